@@ -1,0 +1,278 @@
+/* include/vpt.h — C-ABI of the MI355X volumetric path-tracing integrator (libvpt_hip.so).
+ *
+ * This is the drop-in boundary for ONE function of the reference:
+ *
+ *   void pathtrace_samples(pathtrace_state&, const scene_data&, const bvh_scene&,
+ *                          const pathtrace_lights&, const pathtrace_params&)
+ *                                      libs/yocto_pathtrace/yocto_pathtrace.h:133-135
+ *                                      libs/yocto_pathtrace/yocto_pathtrace.cpp:1052-1092
+ *
+ * The reference has no FFI of its own: its seam is that C++ free
+ * function, whose arguments are STL containers.  The C-ABI below is what a maintainer binds
+ * behind it: plain pointers + counts to the *flattened* forms of the same four inputs
+ * (INTEGRATION.md shows the ~80-line flattening stub for the reference tree).
+ *
+ * Conventions
+ *  - every struct is little-endian POD with the reference's field order where one exists;
+ *  - indices are int32, -1 (VPT_INVALID) == reference `invalidid`;
+ *  - frames are 12 floats, column layout x,y,z,o (yocto_math.h:1099-1107);
+ *  - nothing here owns caller memory: vpt_scene_create() copies everything to the device;
+ *  - all entry points return 0 on success, a negative vpt_status otherwise, and never throw;
+ *    the message for the last failure on the calling thread is vpt_last_error().
+ */
+#ifndef VPT_H_
+#define VPT_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPT_INVALID (-1)
+
+typedef enum vpt_status {
+  VPT_OK                = 0,
+  VPT_ERR_INVALID_ARG   = -1, /* null pointer, bad size, index out of range                */
+  VPT_ERR_NO_DEVICE     = -2, /* no gfx950 device / HIP runtime unavailable                */
+  VPT_ERR_HIP           = -3, /* a HIP call failed (message has hipGetErrorString)         */
+  VPT_ERR_UNKNOWN_SHADER = -4, /* reference: get_shader throws "sampler unknown" (cpp:947) */
+  VPT_ERR_UNSUPPORTED   = -5  /* scene feature outside the hot-path scope (points/lines)   */
+} vpt_status;
+
+/* pathtrace_shader_type, yocto_pathtrace.h:74-84 (same order, same names) */
+typedef enum vpt_shader {
+  VPT_SHADER_VOLPATHTRACE    = 0,
+  VPT_SHADER_PATHTRACE       = 1,
+  VPT_SHADER_NAIVE           = 2,
+  VPT_SHADER_EYELIGHT        = 3,
+  VPT_SHADER_NORMAL          = 4,
+  VPT_SHADER_TEXCOORD        = 5,
+  VPT_SHADER_COLOR           = 6,
+  VPT_SHADER_IMPLICIT        = 7,
+  VPT_SHADER_IMPLICIT_NORMAL = 8
+} vpt_shader;
+
+/* material_type, yocto_scene.h:105-110 */
+typedef enum vpt_material_type {
+  VPT_MAT_MATTE = 0, VPT_MAT_GLOSSY = 1, VPT_MAT_REFLECTIVE = 2, VPT_MAT_TRANSPARENT = 3,
+  VPT_MAT_REFRACTIVE = 4, VPT_MAT_SUBSURFACE = 5, VPT_MAT_VOLUMETRIC = 6, VPT_MAT_GLTFPBR = 7
+} vpt_material_type;
+
+/* sdf_type, yocto_sdfs.h:23 */
+typedef enum vpt_sdf_type {
+  VPT_SDF_BBOX = 0, VPT_SDF_BOX = 1, VPT_SDF_CAPPED_CONE = 2, VPT_SDF_PLANE = 3,
+  VPT_SDF_SPHERE = 4, VPT_SDF_TORUS = 5
+} vpt_sdf_type;
+
+/* frame3f, yocto_math.h:1099-1107 */
+typedef struct vpt_frame { float x[3], y[3], z[3], o[3]; } vpt_frame;
+
+/* camera_data, yocto_scene.h:84-92 */
+typedef struct vpt_camera {
+  vpt_frame frame;
+  int32_t   orthographic;
+  float     lens, film, aspect, focus, aperture;
+} vpt_camera;
+
+/* bvh_node, yocto_bvh.h:73-79 — identical 32-byte layout */
+typedef struct vpt_bvh_node {
+  float   bbox_min[3], bbox_max[3];
+  int32_t start;    /* first child (internal) or first slot in the primitive array (leaf) */
+  int16_t num;      /* 2 (internal) or #primitives (leaf, <= 4)                            */
+  int8_t  axis;     /* split axis                                                          */
+  uint8_t internal; /* bool                                                                */
+} vpt_bvh_node;
+
+/* shape_data, yocto_shape.h:74-87 — offsets into the pooled vertex / element arrays.
+ * Element indices stay shape-local (add *_offset when fetching).  Exactly one of
+ * num_triangles / num_quads is non-zero on the hot path; points/lines are out of scope. */
+typedef struct vpt_shape {
+  int32_t num_vertices;
+  int32_t position_offset;  /* into positions[] (float3 units)                */
+  int32_t normal_offset;    /* into normals[]   (float3 units), -1 if absent  */
+  int32_t texcoord_offset;  /* into texcoords[] (float2 units), -1 if absent  */
+  int32_t color_offset;     /* into colors[]    (float4 units), -1 if absent  */
+  int32_t num_triangles, triangle_offset; /* into triangles[] (int3 units)    */
+  int32_t num_quads, quad_offset;         /* into quads[]     (int4 units)    */
+  int32_t num_bvh_nodes, bvh_node_offset; /* into shape_bvh_nodes[]           */
+  int32_t bvh_prim_offset;                /* into shape_bvh_prims[]           */
+} vpt_shape;
+
+/* instance_data, yocto_scene.h:143-149 */
+typedef struct vpt_instance {
+  vpt_frame frame;
+  int32_t   shape;
+  int32_t   material;
+} vpt_instance;
+
+/* material_data, yocto_scene.h:121-140 */
+typedef struct vpt_material {
+  int32_t type;
+  float   emission[3];
+  float   color[3];
+  float   roughness, metallic, ior;
+  float   scattering[3];
+  float   scanisotropy, trdepth, opacity;
+  int32_t emission_tex, color_tex, roughness_tex, scattering_tex, normal_tex;
+} vpt_material;
+
+/* texture_data, yocto_scene.h:96-102 — pixels live in one of two pools */
+typedef struct vpt_texture {
+  int32_t width, height;
+  int32_t linear;   /* texture_data::linear                                     */
+  int32_t is_float; /* 1: pixelsf (float4 pool), 0: pixelsb (uchar4 pool)       */
+  int64_t offset;   /* first texel, in texels, inside its pool                  */
+} vpt_texture;
+
+/* environment_data, yocto_scene.h:152-157 */
+typedef struct vpt_environment {
+  vpt_frame frame;
+  float     emission[3];
+  int32_t   emission_tex;
+} vpt_environment;
+
+/* volume<float>, yocto_scene.h:203-212 */
+typedef struct vpt_volume {
+  int32_t whd[3];
+  float   res;
+  int64_t offset; /* first voxel inside voxels[]; index x + y*W + z*W*H */
+} vpt_volume;
+
+/* volume_instance, yocto_scene.h:214-219 */
+typedef struct vpt_volume_instance {
+  vpt_frame frame;
+  int32_t   volume;
+  int32_t   material;
+  float     scalef;
+} vpt_volume_instance;
+
+/* sdf_data, yocto_scene.h:194-200.  The reference stores a std::function built in
+ * yocto_sceneio.cpp:3684-3730; here it is a tagged union:
+ *   BBOX        p = {thickness, w, h, d}   sd_bbox(p, {w,h,d}, thickness)
+ *   BOX         uses whd                   sd_box(p - whd/2, whd/2)
+ *   CAPPED_CONE p = {height, r1, r2}
+ *   PLANE       —
+ *   SPHERE      p = {radius}
+ *   TORUS       p = {r1, r2}
+ * `whd` is sdf_data::whd (only set for BOX; used by the SDF light sampling). */
+typedef struct vpt_sdf {
+  vpt_frame frame;
+  int32_t   type;
+  int32_t   material;
+  float     whd[3];
+  float     p[4];
+} vpt_sdf;
+
+/* pathtrace_light, yocto_pathtrace.h:106-111 */
+typedef struct vpt_light {
+  int32_t instance, environment, sdf;
+  int32_t cdf_len;
+  int64_t cdf_offset; /* into light_cdf[] */
+} vpt_light;
+
+/* The flattened (scene_data, bvh_scene, pathtrace_lights) triple. */
+typedef struct vpt_scene_desc {
+  int32_t num_cameras;       const vpt_camera*          cameras;
+  int32_t num_instances;     const vpt_instance*        instances;
+  int32_t num_shapes;        const vpt_shape*           shapes;
+  int32_t num_materials;     const vpt_material*        materials;
+  int32_t num_textures;      const vpt_texture*         textures;
+  int32_t num_environments;  const vpt_environment*     environments;
+  int32_t num_volumes;       const vpt_volume*          volumes;
+  int32_t num_vol_instances; const vpt_volume_instance* vol_instances;
+  int32_t num_sdfs;          const vpt_sdf*             sdfs;
+  int32_t num_lights;        const vpt_light*           lights;
+
+  /* pooled vertex / element data (counts in elements of the stated unit) */
+  int64_t num_positions;  const float*   positions;  /* float3 */
+  int64_t num_normals;    const float*   normals;    /* float3 */
+  int64_t num_texcoords;  const float*   texcoords;  /* float2 */
+  int64_t num_colors;     const float*   colors;     /* float4 */
+  int64_t num_triangles;  const int32_t* triangles;  /* int3   */
+  int64_t num_quads;      const int32_t* quads;      /* int4   */
+
+  /* texture / voxel / cdf pools */
+  int64_t num_texels_f;   const float*   texels_f;   /* float4 */
+  int64_t num_texels_b;   const uint8_t* texels_b;   /* uchar4 */
+  int64_t num_voxels;     const float*   voxels;
+  int64_t num_light_cdf;  const float*   light_cdf;
+
+  /* two-level BVH, bvh_data yocto_bvh.h:87-92 */
+  int32_t num_scene_bvh_nodes;  const vpt_bvh_node* scene_bvh_nodes;
+  int32_t num_scene_bvh_prims;  const int32_t*      scene_bvh_prims; /* instance ids */
+  int64_t num_shape_bvh_nodes;  const vpt_bvh_node* shape_bvh_nodes; /* pooled */
+  int64_t num_shape_bvh_prims;  const int32_t*      shape_bvh_prims; /* pooled, element ids */
+} vpt_scene_desc;
+
+/* pathtrace_params, yocto_pathtrace.h:87-99 (fields the path reads) */
+typedef struct vpt_params {
+  int32_t camera;
+  int32_t resolution;
+  int32_t shader;   /* vpt_shader */
+  int32_t samples;  /* total samples requested: the call is a no-op once reached (cpp:1055);
+                       ==1 selects the pixel-centre preview branch (cpp:1059-1068)          */
+  int32_t bounces;
+  int32_t noparallel;          /* accepted, ignored (one lane per pixel)                    */
+  int32_t noimplicit_mis;
+  int32_t spheretrace_maxiter;
+} vpt_params;
+
+typedef struct vpt_scene vpt_scene; /* opaque device-side scene */
+
+/* How pixels are laid out in device-resident state and shared between GPUs.
+ * The image is cut into tile_w x tile_h pixel tiles (row-major tile order); tile t belongs
+ * to rank (t % nranks) and is that rank's local tile (t / nranks).  A rank's state arrays are
+ * TILE-MAJOR and compact: local index l = local_tile * (tile_w*tile_h) + (py*tile_w + px).
+ * Slots whose pixel falls outside the image are padding and never touched. */
+typedef struct vpt_layout {
+  int32_t width, height;
+  int32_t tile_w, tile_h; /* tile_w*tile_h must be a multiple of 64 (one wave64 per 8x8) */
+  int32_t rank, nranks;
+} vpt_layout;
+
+/* ---- queries ----------------------------------------------------------------------- */
+int         vpt_device_count(void);
+const char* vpt_last_error(void);
+const char* vpt_version(void);
+
+/* ---- scene ------------------------------------------------------------------------- */
+/* Validates every index/offset in `desc` against its pool, precomputes
+ * inverse(frame, non_rigid=true) per instance with the reference's adjoint/determinant
+ * formula (yocto_math.h:2802-2808, 2948-2956), uploads to `device`.                      */
+int  vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out);
+void vpt_scene_destroy(vpt_scene* scene);
+
+/* ---- the drop-in for pathtrace_samples() --------------------------------------------
+ * Host, row-major (idx = j*width + i) caller-owned state, exactly pathtrace_state
+ * (yocto_pathtrace.h:57-64): image float4[w*h], hits int32[w*h], rng {u64 state, u64 inc}[w*h].
+ * Renders min(nsamples, params->samples - *samples_io) passes; the result equals that many
+ * consecutive reference calls.  *samples_io is state.samples (in/out).                    */
+int vpt_render(vpt_scene* scene, const vpt_params* params, int nsamples, int width, int height,
+               float* image_rgba, int32_t* hits, uint64_t* rng, int* samples_io);
+
+/* ---- device-resident state (bench / multi-GPU; buffers owned by the caller, e.g. torch) */
+/* number of state slots a rank needs for `layout` (multiple of tile_w*tile_h) */
+int64_t vpt_layout_slots(const vpt_layout* layout);
+/* host row-major <-> device tile-major (only this rank's pixels are touched) */
+int vpt_state_upload(const vpt_layout* layout, const float* image_rgba, const int32_t* hits,
+                     const uint64_t* rng, void* d_image, void* d_hits, void* d_rng, void* stream);
+int vpt_state_download(const vpt_layout* layout, const void* d_image, const void* d_hits,
+                       const void* d_rng, float* image_rgba, int32_t* hits, uint64_t* rng,
+                       void* stream);
+/* nsamples passes over this rank's pixels; asynchronous on `stream` (hipStream_t).
+ * `first_sample` is state.samples before the call (selects the samples==1 preview branch). */
+int vpt_render_device(vpt_scene* scene, const vpt_params* params, const vpt_layout* layout,
+                      int nsamples, void* d_image, void* d_hits, void* d_rng, void* stream);
+/* get_render (yocto_pathtrace.cpp:1105-1116) on device: gathered tile-major float4 sums of ALL
+ * ranks ([nranks][slots]) -> row-major float4 image * (1/samples).                          */
+int vpt_resolve_device(const vpt_layout* layout, const void* d_tiles_all_ranks, int samples,
+                       void* d_image_rowmajor, void* stream);
+
+/* per-launch profile of the last vpt_render_device on this scene (HIP events on `stream`) */
+int vpt_last_kernel_ms(vpt_scene* scene, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPT_H_ */

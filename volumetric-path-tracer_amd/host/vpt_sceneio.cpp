@@ -1,0 +1,866 @@
+// vpt_sceneio.cpp — the subset of the reference's scene/asset IO that the hot path's callers
+// need: JSON scene format 4.2 (yocto_sceneio.cpp:3544-3865), PLY meshes
+// (yocto_modelio.cpp:1117-1231 semantics: quads-vs-triangles rule, texcoord v-flip), PNG -> RGBA8,
+// Radiance HDR -> float4 (stb_image.h:7046-7071 conversion), `.sdf` voxel grids
+// (yocto_sceneio.cpp:885-967).  Written from the file formats, not from the reference's parsers.
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+
+#include "vpt_host.h"
+
+namespace vpt {
+
+// ---------------------------------------------------------------------------------------------
+// files
+// ---------------------------------------------------------------------------------------------
+static bool read_file(const string& filename, vector<uint8_t>& data, string& error) {
+  auto f = fopen(filename.c_str(), "rb");
+  if (!f) {
+    error = filename + ": file not found";
+    return false;
+  }
+  fseek(f, 0, SEEK_END);
+  auto n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  data.resize((size_t)n);
+  auto ok = n == 0 || fread(data.data(), 1, (size_t)n, f) == (size_t)n;
+  fclose(f);
+  if (!ok) error = filename + ": read error";
+  return ok;
+}
+static string path_dirname(const string& filename) {
+  auto pos = filename.find_last_of("/\\");
+  return pos == string::npos ? string{"."} : filename.substr(0, pos);
+}
+static string path_extension(const string& filename) {
+  auto pos = filename.rfind('.');
+  if (pos == string::npos) return "";
+  auto ext = filename.substr(pos);
+  for (auto& c : ext) c = (char)tolower(c);
+  return ext;
+}
+static string path_join(const string& a, const string& b) { return a + "/" + b; }
+
+// ---------------------------------------------------------------------------------------------
+// minimal JSON (RFC 8259) — numbers kept as double (strtod), converted on access like the
+// reference's json.value<float>()
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct json_value {
+  enum kind_t { null_k, bool_k, number_k, string_k, array_k, object_k } kind = null_k;
+  bool                                       boolean = false;
+  double                                     number  = 0;
+  string                                     text;
+  vector<json_value>                         items;
+  vector<std::pair<string, json_value>>      members;
+  const json_value* find(const string& key) const {
+    for (auto& [k, v] : members)
+      if (k == key) return &v;
+    return nullptr;
+  }
+};
+struct json_parser {
+  const char* p;
+  const char* end;
+  void ws() {
+    while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++;
+  }
+  [[noreturn]] void fail() { throw std::runtime_error{"json"}; }
+  json_value parse() {
+    ws();
+    if (p >= end) fail();
+    auto v = json_value{};
+    if (*p == '{') {
+      v.kind = json_value::object_k;
+      p++, ws();
+      if (p < end && *p == '}') return p++, v;
+      while (true) {
+        ws();
+        auto key = parse_string();
+        ws();
+        if (p >= end || *p++ != ':') fail();
+        v.members.emplace_back(key, parse());
+        ws();
+        if (p >= end) fail();
+        if (*p == ',') { p++; continue; }
+        if (*p == '}') return p++, v;
+        fail();
+      }
+    } else if (*p == '[') {
+      v.kind = json_value::array_k;
+      p++, ws();
+      if (p < end && *p == ']') return p++, v;
+      while (true) {
+        v.items.push_back(parse());
+        ws();
+        if (p >= end) fail();
+        if (*p == ',') { p++; continue; }
+        if (*p == ']') return p++, v;
+        fail();
+      }
+    } else if (*p == '"') {
+      v.kind = json_value::string_k, v.text = parse_string();
+    } else if (!strncmp(p, "true", 4) && end - p >= 4) {
+      v.kind = json_value::bool_k, v.boolean = true, p += 4;
+    } else if (!strncmp(p, "false", 5) && end - p >= 5) {
+      v.kind = json_value::bool_k, v.boolean = false, p += 5;
+    } else if (!strncmp(p, "null", 4) && end - p >= 4) {
+      p += 4;
+    } else {
+      auto next = (char*)nullptr;
+      v.kind = json_value::number_k, v.number = strtod(p, &next);
+      if (next == p) fail();
+      p = next;
+    }
+    return v;
+  }
+  string parse_string() {
+    if (p >= end || *p != '"') fail();
+    p++;
+    auto s = string{};
+    while (p < end && *p != '"') {
+      if (*p == '\\') {
+        p++;
+        if (p >= end) fail();
+        switch (*p) {
+          case 'n': s += '\n'; break;
+          case 't': s += '\t'; break;
+          case 'r': s += '\r'; break;
+          case 'b': s += '\b'; break;
+          case 'f': s += '\f'; break;
+          case 'u': {  // BMP code point -> UTF-8
+            if (end - p < 5) fail();
+            auto cp = (unsigned)strtoul(string(p + 1, p + 5).c_str(), nullptr, 16);
+            p += 4;
+            if (cp < 0x80) s += (char)cp;
+            else if (cp < 0x800) s += (char)(0xc0 | (cp >> 6)), s += (char)(0x80 | (cp & 0x3f));
+            else s += (char)(0xe0 | (cp >> 12)), s += (char)(0x80 | ((cp >> 6) & 0x3f)), s += (char)(0x80 | (cp & 0x3f));
+          } break;
+          default: s += *p;
+        }
+        p++;
+      } else {
+        s += *p++;
+      }
+    }
+    if (p >= end) fail();
+    p++;
+    return s;
+  }
+};
+
+// get_opt family: leave `value` untouched when the key is absent (json.value(key, default))
+void get_opt(const json_value& js, const char* key, float& value) {
+  if (auto v = js.find(key)) {
+    if (v->kind != json_value::number_k) throw std::runtime_error{"json"};
+    value = (float)v->number;
+  }
+}
+void get_opt(const json_value& js, const char* key, int& value) {
+  if (auto v = js.find(key)) {
+    if (v->kind != json_value::number_k) throw std::runtime_error{"json"};
+    value = (int)v->number;
+  }
+}
+void get_opt(const json_value& js, const char* key, bool& value) {
+  if (auto v = js.find(key)) {
+    if (v->kind != json_value::bool_k) throw std::runtime_error{"json"};
+    value = v->boolean;
+  }
+}
+void get_opt(const json_value& js, const char* key, string& value) {
+  if (auto v = js.find(key)) {
+    if (v->kind != json_value::string_k) throw std::runtime_error{"json"};
+    value = v->text;
+  }
+}
+void get_floats(const json_value& js, const char* key, float* out, size_t n) {
+  if (auto v = js.find(key)) {
+    if (v->kind != json_value::array_k || v->items.size() != n) throw std::runtime_error{"json"};
+    for (size_t i = 0; i < n; i++) {
+      if (v->items[i].kind != json_value::number_k) throw std::runtime_error{"json"};
+      out[i] = (float)v->items[i].number;
+    }
+  }
+}
+void get_opt(const json_value& js, const char* key, vec3f& value) { get_floats(js, key, &value.x, 3); }
+void get_opt(const json_value& js, const char* key, frame3f& value) { get_floats(js, key, &value.x.x, 12); }
+template <typename E>
+void get_enum(const json_value& js, const char* key, E& value, const vector<string>& names) {
+  if (auto v = js.find(key)) {
+    if (v->kind != json_value::string_k) throw std::runtime_error{"json"};
+    // nlohmann's enum mapping falls back to the FIRST entry for unknown names
+    value = (E)0;
+    for (size_t i = 0; i < names.size(); i++)
+      if (names[i] == v->text) value = (E)i;
+  }
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// PLY
+// ---------------------------------------------------------------------------------------------
+namespace {
+enum ply_type { t_i8, t_u8, t_i16, t_u16, t_i32, t_u32, t_f32, t_f64, t_bad };
+ply_type parse_ply_type(const string& s) {
+  if (s == "char" || s == "int8") return t_i8;
+  if (s == "uchar" || s == "uint8") return t_u8;
+  if (s == "short" || s == "int16") return t_i16;
+  if (s == "ushort" || s == "uint16") return t_u16;
+  if (s == "int" || s == "int32") return t_i32;
+  if (s == "uint" || s == "uint32") return t_u32;
+  if (s == "float" || s == "float32") return t_f32;
+  if (s == "double" || s == "float64") return t_f64;
+  return t_bad;
+}
+int ply_size(ply_type t) {
+  static const int sizes[] = {1, 1, 2, 2, 4, 4, 4, 8, 0};
+  return sizes[t];
+}
+struct ply_property {
+  string         name;
+  bool           is_list = false;
+  ply_type       type = t_bad, ltype = t_bad;
+  vector<double> values;        // scalar: one per element; list: concatenated
+  vector<int>    list_sizes;    // list only
+};
+struct ply_element {
+  string               name;
+  size_t               count = 0;
+  vector<ply_property> props;
+  const ply_property* find(const string& n) const {
+    for (auto& p : props)
+      if (p.name == n) return &p;
+    return nullptr;
+  }
+};
+double read_binary(const uint8_t*& p, const uint8_t* end, ply_type t, bool big_endian) {
+  auto n = ply_size(t);
+  if (end - p < n) throw std::runtime_error{"ply"};
+  uint8_t b[8];
+  for (auto i = 0; i < n; i++) b[i] = big_endian ? p[n - 1 - i] : p[i];
+  p += n;
+  switch (t) {
+    case t_i8: { int8_t v; memcpy(&v, b, 1); return v; }
+    case t_u8: { uint8_t v; memcpy(&v, b, 1); return v; }
+    case t_i16: { int16_t v; memcpy(&v, b, 2); return v; }
+    case t_u16: { uint16_t v; memcpy(&v, b, 2); return v; }
+    case t_i32: { int32_t v; memcpy(&v, b, 4); return v; }
+    case t_u32: { uint32_t v; memcpy(&v, b, 4); return v; }
+    case t_f32: { float v; memcpy(&v, b, 4); return v; }
+    case t_f64: { double v; memcpy(&v, b, 8); return v; }
+    default: throw std::runtime_error{"ply"};
+  }
+}
+}  // namespace
+
+bool load_shape(const string& filename, shape_data& shape, string& error, bool flip_texcoord) {
+  shape    = {};
+  auto ext = path_extension(filename);
+  if (ext != ".ply") {
+    error = filename + ": unknown format";  // OBJ/STL are outside the hot-path scope
+    return false;
+  }
+  auto data = vector<uint8_t>{};
+  if (!read_file(filename, data, error)) return false;
+  auto read_error = [&]() {
+    error = filename + ": read error";
+    return false;
+  };
+  auto elements = vector<ply_element>{};
+  try {
+    // header
+    const uint8_t* p   = data.data();
+    const uint8_t* end = data.data() + data.size();
+    auto next_line = [&]() {
+      auto s = string{};
+      while (p < end && *p != '\n') s += (char)*p++;
+      if (p < end) p++;
+      if (!s.empty() && s.back() == '\r') s.pop_back();
+      return s;
+    };
+    if (next_line() != "ply") return read_error();
+    auto format = string{};
+    while (true) {
+      if (p >= end) return read_error();
+      auto line = next_line();
+      auto ss   = std::istringstream{line};
+      auto cmd  = string{};
+      ss >> cmd;
+      if (cmd == "format") ss >> format;
+      else if (cmd == "element") {
+        auto& e = elements.emplace_back();
+        ss >> e.name >> e.count;
+      } else if (cmd == "property") {
+        if (elements.empty()) return read_error();
+        auto& prop = elements.back().props.emplace_back();
+        auto  t    = string{};
+        ss >> t;
+        if (t == "list") {
+          auto lt = string{}, vt = string{};
+          ss >> lt >> vt >> prop.name;
+          prop.is_list = true, prop.ltype = parse_ply_type(lt), prop.type = parse_ply_type(vt);
+          if (prop.ltype == t_bad) return read_error();
+        } else {
+          prop.type = parse_ply_type(t);
+          ss >> prop.name;
+        }
+        if (prop.type == t_bad) return read_error();
+      } else if (cmd == "end_header") break;
+    }
+    auto ascii = format == "ascii", big = format == "binary_big_endian";
+    if (!ascii && !big && format != "binary_little_endian") return read_error();
+    // body
+    auto text = std::istringstream{};
+    if (ascii) text.str(string((const char*)p, (size_t)(end - p)));
+    auto next = [&](ply_type t) -> double {
+      if (!ascii) return read_binary(p, end, t, big);
+      auto v = 0.0;
+      if (!(text >> v)) throw std::runtime_error{"ply"};
+      return v;
+    };
+    for (auto& e : elements) {
+      for (auto& prop : e.props) {
+        if (prop.is_list) prop.list_sizes.reserve(e.count);
+        prop.values.reserve(e.count * (prop.is_list ? 4 : 1));
+      }
+      for (size_t i = 0; i < e.count; i++)
+        for (auto& prop : e.props) {
+          if (prop.is_list) {
+            auto n = (int)next(prop.ltype);
+            prop.list_sizes.push_back(n);
+            for (auto k = 0; k < n; k++) prop.values.push_back(next(prop.type));
+          } else {
+            prop.values.push_back(next(prop.type));
+          }
+        }
+    }
+  } catch (...) {
+    return read_error();
+  }
+  // vertex attributes -> float32 (get_positions/normals/texcoords/colors, yocto_modelio.cpp:1124-1160)
+  for (auto& e : elements) {
+    if (e.name == "vertex") {
+      auto get = [&](std::initializer_list<const char*> names, size_t n, float* out, size_t stride) {
+        auto k = (size_t)0;
+        for (auto name : names) {
+          auto prop = e.find(name);
+          if (!prop || prop->is_list) return false;
+          for (size_t i = 0; i < n; i++) out[i * stride + k] = (float)prop->values[i];
+          k++;
+        }
+        return true;
+      };
+      auto n = e.count;
+      if (e.find("x") && e.find("y") && e.find("z")) {
+        shape.positions.resize(n);
+        get({"x", "y", "z"}, n, &shape.positions[0].x, 3);
+      }
+      if (e.find("nx") && e.find("ny") && e.find("nz")) {
+        shape.normals.resize(n);
+        get({"nx", "ny", "nz"}, n, &shape.normals[0].x, 3);
+      }
+      if ((e.find("u") && e.find("v")) || (e.find("s") && e.find("t"))) {
+        shape.texcoords.resize(n);
+        if (e.find("u")) get({"u", "v"}, n, &shape.texcoords[0].x, 2);
+        else get({"s", "t"}, n, &shape.texcoords[0].x, 2);
+        if (flip_texcoord)
+          for (auto& uv : shape.texcoords) uv.y = 1 - uv.y;
+      }
+      if (e.find("red") && e.find("green") && e.find("blue")) {
+        shape.colors.resize(n);
+        get({"red", "green", "blue"}, n, &shape.colors[0].x, 4);
+        if (e.find("alpha")) get({"alpha"}, n, &shape.colors[0].w, 4);
+        else for (auto& c : shape.colors) c.w = 1;
+        // 8-bit colours are normalised
+        auto scale = e.find("red")->type == t_u8 ? 1 / 255.0f : 1.0f;
+        if (scale != 1.0f)
+          for (auto& c : shape.colors) c = {c.x * scale, c.y * scale, c.z * scale, e.find("alpha") ? c.w * scale : 1.0f};
+      }
+    } else if (e.name == "face") {
+      auto prop = e.find("vertex_indices");
+      if (!prop) prop = e.find("vertex_index");
+      if (!prop || !prop->is_list) continue;
+      // has_quads (yocto_modelio.cpp:1226-1232): ANY 4-sided face turns the whole mesh into quads,
+      // triangles becoming degenerate quads (z == w); otherwise polygons are fanned into triangles.
+      auto any_quad = false;
+      for (auto n : prop->list_sizes) any_quad |= n == 4;
+      auto cur = (size_t)0;
+      for (auto n : prop->list_sizes) {
+        auto idx = [&](int k) { return (int)prop->values[cur + (size_t)k]; };
+        if (any_quad) {
+          if (n == 4) shape.quads.push_back({idx(0), idx(1), idx(2), idx(3)});
+          else for (auto c = 2; c < n; c++) shape.quads.push_back({idx(0), idx(c - 1), idx(c), idx(c)});
+        } else {
+          for (auto c = 2; c < n; c++) shape.triangles.push_back({idx(0), idx(c - 1), idx(c)});
+        }
+        cur += (size_t)n;
+      }
+    } else if (e.name == "point") {
+      if (auto prop = e.find("vertex_indices"))
+        for (auto v : prop->values) shape.points.push_back((int)v);
+    }
+  }
+  // reject out-of-range indices here rather than on the device
+  auto nv = (int)shape.positions.size();
+  for (auto& t : shape.triangles)
+    if (t.x < 0 || t.y < 0 || t.z < 0 || t.x >= nv || t.y >= nv || t.z >= nv) return read_error();
+  for (auto& q : shape.quads)
+    if (q.x < 0 || q.y < 0 || q.z < 0 || q.w < 0 || q.x >= nv || q.y >= nv || q.z >= nv || q.w >= nv)
+      return read_error();
+  if (shape.points.empty() && shape.triangles.empty() && shape.quads.empty()) {
+    error = filename + ": empty shape";
+    return false;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PNG (8/16-bit, all colour types, non-interlaced) -> RGBA8 ; Radiance HDR -> float4
+// ---------------------------------------------------------------------------------------------
+static bool zlib_inflate(const vector<uint8_t>& in, vector<uint8_t>& out, size_t expected) {
+  out.resize(expected);
+  auto n = (uLongf)expected;
+  return uncompress(out.data(), &n, in.data(), (uLong)in.size()) == Z_OK && n == expected;
+}
+
+static bool decode_png(const vector<uint8_t>& data, texture_data& texture) {
+  static const uint8_t magic[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+  if (data.size() < 8 || memcmp(data.data(), magic, 8)) return false;
+  auto be32 = [&](size_t o) { return (uint32_t)data[o] << 24 | (uint32_t)data[o + 1] << 16 | (uint32_t)data[o + 2] << 8 | data[o + 3]; };
+  auto width = 0u, height = 0u;
+  auto depth = 0, ctype = 0, interlace = 0;
+  auto idat    = vector<uint8_t>{};
+  auto palette = vector<uint8_t>{}, trns = vector<uint8_t>{};
+  auto pos     = (size_t)8;
+  while (pos + 8 <= data.size()) {
+    auto len  = be32(pos);
+    auto type = string((const char*)&data[pos + 4], 4);
+    auto body = pos + 8;
+    if (body + len + 4 > data.size()) return false;
+    if (type == "IHDR") {
+      if (len < 13) return false;
+      width = be32(body), height = be32(body + 4);
+      depth = data[body + 8], ctype = data[body + 9], interlace = data[body + 12];
+    } else if (type == "PLTE") palette.assign(&data[body], &data[body] + len);
+    else if (type == "tRNS") trns.assign(&data[body], &data[body] + len);
+    else if (type == "IDAT") idat.insert(idat.end(), &data[body], &data[body] + len);
+    else if (type == "IEND") break;
+    pos = body + len + 4;
+  }
+  if (!width || !height || interlace || (depth != 8 && depth != 16)) return false;
+  auto channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+  if (!channels || (ctype == 3 && depth != 8)) return false;
+  auto bpp    = (size_t)channels * (depth / 8);
+  auto stride = (size_t)width * bpp;
+  auto raw    = vector<uint8_t>{};
+  if (!zlib_inflate(idat, raw, (stride + 1) * height)) return false;
+  auto pix  = vector<uint8_t>(stride * height);
+  auto prev = vector<uint8_t>(stride, 0);
+  for (size_t y = 0; y < height; y++) {
+    auto filter = raw[y * (stride + 1)];
+    auto src    = &raw[y * (stride + 1) + 1];
+    auto dst    = &pix[y * stride];
+    for (size_t x = 0; x < stride; x++) {
+      int a = x >= bpp ? dst[x - bpp] : 0, b = prev[x], c = x >= bpp ? prev[x - bpp] : 0;
+      auto v = 0;
+      switch (filter) {
+        case 0: v = 0; break;
+        case 1: v = a; break;
+        case 2: v = b; break;
+        case 3: v = (a + b) / 2; break;
+        case 4: {
+          auto pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c);
+          v = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+        } break;
+        default: return false;
+      }
+      dst[x] = (uint8_t)(src[x] + v);
+    }
+    memcpy(prev.data(), dst, stride);
+  }
+  texture.width = (int)width, texture.height = (int)height, texture.linear = false;
+  texture.pixelsf.clear();
+  texture.pixelsb.resize((size_t)width * height);
+  auto step = depth / 8;  // 16-bit: keep the high byte
+  for (size_t i = 0; i < (size_t)width * height; i++) {
+    auto s  = &pix[i * bpp];
+    auto& o = texture.pixelsb[i];
+    switch (ctype) {
+      case 0: o = {s[0], s[0], s[0], 255}; break;
+      case 2: o = {s[0], s[step], s[2 * step], 255}; break;
+      case 3: {
+        auto k = (size_t)s[0];
+        if (3 * k + 2 >= palette.size()) return false;
+        o = {palette[3 * k], palette[3 * k + 1], palette[3 * k + 2], k < trns.size() ? trns[k] : (uint8_t)255};
+      } break;
+      case 4: o = {s[0], s[0], s[0], s[step]}; break;
+      case 6: o = {s[0], s[step], s[2 * step], s[3 * step]}; break;
+    }
+  }
+  return true;
+}
+
+static bool decode_hdr(const vector<uint8_t>& data, texture_data& texture) {
+  auto p = data.data(), end = data.data() + data.size();
+  auto next_line = [&]() {
+    auto s = string{};
+    while (p < end && *p != '\n') s += (char)*p++;
+    if (p < end) p++;
+    return s;
+  };
+  auto first = next_line();
+  if (first != "#?RADIANCE" && first != "#?RGBE") return false;
+  auto valid = false;
+  while (p < end) {
+    auto line = next_line();
+    if (line.empty()) break;
+    if (line == "FORMAT=32-bit_rle_rgbe") valid = true;
+  }
+  if (!valid) return false;
+  auto dims  = next_line();
+  auto width = 0, height = 0;
+  if (sscanf(dims.c_str(), "-Y %d +X %d", &height, &width) != 2 || width <= 0 || height <= 0) return false;
+  auto rgbe = vector<uint8_t>((size_t)width * height * 4);
+  auto flat = [&](size_t from_pixel) {
+    auto need = ((size_t)width * height - from_pixel) * 4;
+    if ((size_t)(end - p) < need) return false;
+    memcpy(&rgbe[from_pixel * 4], p, need);
+    return true;
+  };
+  if (width < 8 || width >= 32768) {
+    if (!flat(0)) return false;
+  } else {
+    for (auto j = 0; j < height; j++) {
+      if (end - p < 4) return false;
+      if (p[0] != 2 || p[1] != 2 || (p[2] & 0x80)) {
+        if (j != 0) return false;  // stb only accepts a flat file decided on the first scanline
+        if (!flat(0)) return false;
+        break;
+      }
+      if (((int)p[2] << 8 | p[3]) != width) return false;
+      p += 4;
+      auto row = &rgbe[(size_t)j * width * 4];
+      for (auto k = 0; k < 4; k++) {
+        auto i = 0;
+        while (i < width) {
+          if (p >= end) return false;
+          auto count = (int)*p++;
+          if (count > 128) {
+            count -= 128;
+            if (p >= end || count == 0 || i + count > width) return false;
+            auto value = *p++;
+            for (auto z = 0; z < count; z++) row[(i++) * 4 + k] = value;
+          } else {
+            if (count == 0 || i + count > width || end - p < count) return false;
+            for (auto z = 0; z < count; z++) row[(i++) * 4 + k] = *p++;
+          }
+        }
+      }
+    }
+  }
+  texture.width = width, texture.height = height, texture.linear = true;
+  texture.pixelsb.clear();
+  texture.pixelsf.resize((size_t)width * height);
+  for (size_t i = 0; i < texture.pixelsf.size(); i++) {
+    auto s = &rgbe[i * 4];
+    if (s[3] != 0) {
+      auto f = (float)ldexp(1.0f, (int)s[3] - (128 + 8));
+      texture.pixelsf[i] = {s[0] * f, s[1] * f, s[2] * f, 1};
+    } else {
+      texture.pixelsf[i] = {0, 0, 0, 1};
+    }
+  }
+  return true;
+}
+
+bool load_texture(const string& filename, texture_data& texture, string& error) {
+  auto ext  = path_extension(filename);
+  auto data = vector<uint8_t>{};
+  if (ext != ".png" && ext != ".hdr") {
+    error = filename + ": unknown format";
+    return false;
+  }
+  if (!read_file(filename, data, error)) return false;
+  auto ok = ext == ".png" ? decode_png(data, texture) : decode_hdr(data, texture);
+  if (!ok) error = filename + ": rad error";  // (sic) the reference's message, yocto_sceneio.cpp:1740
+  return ok;
+}
+
+// ---------------------------------------------------------------------------------------------
+// .sdf voxel grids, yocto_sceneio.cpp:885-967
+// ---------------------------------------------------------------------------------------------
+bool load_volume(const string& filename, volume_data& vol, bool binary, string& error) {
+  auto data = vector<uint8_t>{};
+  if (!read_file(filename, data, error)) {
+    error = filename + ": read error";
+    return false;
+  }
+  vol = {};
+  if (binary) {
+    // int32 w,h,d ; float res ; 16 floats (ignored) ; w*h*d floats
+    if (data.size() < 16 + 64) { error = filename + ": read error"; return false; }
+    int32_t whd[3];
+    memcpy(whd, data.data(), 12);
+    memcpy(&vol.res, data.data() + 12, 4);
+    auto n = (size_t)whd[0] * whd[1] * whd[2];
+    if (whd[0] <= 0 || whd[1] <= 0 || whd[2] <= 0 || data.size() < 80 + n * 4) { error = filename + ": read error"; return false; }
+    vol.vol.resize(n);
+    memcpy(vol.vol.data(), data.data() + 80, n * 4);
+    vol.whd = {whd[0], whd[1], whd[2]};
+    return true;
+  }
+  // text (SDFGen): "W H D" / origin line (ignored) / cell size / values, x fastest
+  auto text  = string((const char*)data.data(), data.size());
+  auto lines = std::istringstream{text};
+  auto line  = string{};
+  auto count = 0;
+  while (std::getline(lines, line)) {
+    if (count == 0) {
+      auto w = 0, h = 0, d = 0;
+      if (sscanf(line.c_str(), "%d %d %d", &w, &h, &d) != 3) { error = filename + ": read error"; return false; }
+      vol.whd = {w, h, d};
+    } else if (count == 2) {
+      vol.res = (float)atof(line.c_str());
+    } else if (count > 2) {
+      auto p = line.c_str();
+      while (*p) {
+        while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') p++;
+        if (!*p) break;
+        auto q = p;
+        while (*q && *q != ' ' && *q != '\t' && *q != '\r' && *q != '\n') q++;
+        vol.vol.push_back((float)atof(string(p, q).c_str()));
+        p = q;
+      }
+    }
+    count++;
+  }
+  if ((size_t)vol.whd.x * vol.whd.y * vol.whd.z > vol.vol.size() || vol.vol.empty()) {
+    error = filename + ": read error";
+    return false;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// JSON scene 4.2
+// ---------------------------------------------------------------------------------------------
+bool load_scene(const string& filename, scene_data& scene, string& error) {
+  scene    = {};
+  auto ext = path_extension(filename);
+  if (ext != ".json") {
+    error = filename + ": unknown format";
+    return false;
+  }
+  auto data = vector<uint8_t>{};
+  if (!read_file(filename, data, error)) return false;
+  auto parse_error = [&]() {
+    error = filename + ": parse error";
+    return false;
+  };
+  auto shape_uris = vector<string>{}, texture_uris = vector<string>{}, volume_uris = vector<string>{};
+  auto volume_binary = vector<bool>{};
+  try {
+    auto parser = json_parser{(const char*)data.data(), (const char*)data.data() + data.size()};
+    auto js     = parser.parse();
+    if (js.kind != json_value::object_k) return parse_error();
+    auto version = string{};
+    if (auto asset = js.find("asset")) {
+      get_opt(*asset, "copyright", scene.copyright);
+      get_opt(*asset, "version", version);
+    }
+    if (version != "4.2" && version != "5.0") return parse_error();  // 4.0/4.1 dialects: out of scope
+    static const json_value empty{};
+    auto group = [&](const char* name) -> const vector<json_value>& {
+      auto g = js.find(name);
+      if (!g) return empty.items;
+      if (g->kind != json_value::array_k) throw std::runtime_error{"json"};
+      return g->items;
+    };
+    for (auto& e : group("cameras")) {
+      auto& camera = scene.cameras.emplace_back();
+      get_opt(e, "frame", camera.frame), get_opt(e, "orthographic", camera.orthographic);
+      get_opt(e, "lens", camera.lens), get_opt(e, "aspect", camera.aspect), get_opt(e, "film", camera.film);
+      get_opt(e, "focus", camera.focus), get_opt(e, "aperture", camera.aperture);
+    }
+    for (auto& e : group("textures")) {
+      scene.textures.emplace_back();
+      get_opt(e, "uri", texture_uris.emplace_back());
+    }
+    for (auto& e : group("materials")) {
+      auto& m = scene.materials.emplace_back();
+      get_enum(e, "type", m.type, material_type_names);
+      get_opt(e, "emission", m.emission), get_opt(e, "color", m.color), get_opt(e, "metallic", m.metallic);
+      get_opt(e, "roughness", m.roughness), get_opt(e, "ior", m.ior), get_opt(e, "trdepth", m.trdepth);
+      get_opt(e, "scattering", m.scattering), get_opt(e, "scanisotropy", m.scanisotropy);
+      get_opt(e, "opacity", m.opacity), get_opt(e, "emission_tex", m.emission_tex);
+      get_opt(e, "color_tex", m.color_tex), get_opt(e, "roughness_tex", m.roughness_tex);
+      get_opt(e, "scattering_tex", m.scattering_tex), get_opt(e, "normal_tex", m.normal_tex);
+    }
+    for (auto& e : group("shapes")) {
+      scene.shapes.emplace_back();
+      get_opt(e, "uri", shape_uris.emplace_back());
+    }
+    for (auto& e : group("volumes")) {
+      scene.volumes.emplace_back();
+      auto binary = false;
+      get_opt(e, "binary", binary);
+      volume_binary.push_back(binary);
+      get_opt(e, "uri", volume_uris.emplace_back());
+    }
+    for (auto& e : group("sdfunctions")) {
+      auto& sdf = scene.sdfs.emplace_back();
+      sdf.type  = sdf_type::bbox;  // enum fallback = first entry
+      get_enum(e, "type", sdf.type, sdf_type_names);
+      get_opt(e, "frame", sdf.frame), get_opt(e, "material", sdf.material);
+      switch (sdf.type) {
+        case sdf_type::bbox: {
+          auto whd = vec3f{};
+          get_opt(e, "thickness", sdf.p[0]), get_opt(e, "whd", whd);
+          sdf.p[1] = whd.x, sdf.p[2] = whd.y, sdf.p[3] = whd.z;  // sdf.whd stays 0 (sceneio:3685-3692)
+        } break;
+        case sdf_type::box: get_opt(e, "whd", sdf.whd); break;
+        case sdf_type::capped_cone:
+          get_opt(e, "height", sdf.p[0]), get_opt(e, "r1", sdf.p[1]), get_opt(e, "r2", sdf.p[2]);
+          break;
+        case sdf_type::plane: break;
+        case sdf_type::sphere: get_opt(e, "radius", sdf.p[0]); break;
+        case sdf_type::torus: get_opt(e, "r1", sdf.p[0]), get_opt(e, "r2", sdf.p[1]); break;
+      }
+    }
+    scene.num_subdivs = (int)group("subdivs").size();
+    for (auto& e : group("instances")) {
+      auto& instance = scene.instances.emplace_back();
+      get_opt(e, "frame", instance.frame), get_opt(e, "shape", instance.shape);
+      get_opt(e, "material", instance.material);
+    }
+    for (auto& e : group("vol_instances")) {
+      auto& instance = scene.vol_instances.emplace_back();
+      get_opt(e, "frame", instance.frame), get_opt(e, "volume", instance.volume);
+      get_opt(e, "scale", instance.scalef), get_opt(e, "material", instance.material);
+    }
+    for (auto& e : group("environments")) {
+      auto& environment = scene.environments.emplace_back();
+      get_opt(e, "frame", environment.frame), get_opt(e, "emission", environment.emission);
+      get_opt(e, "emission_tex", environment.emission_tex);
+    }
+  } catch (...) {
+    return parse_error();
+  }
+
+  auto dirname = path_dirname(filename);
+  auto dependent_error = [&]() {
+    error = filename + ": error in " + error;
+    return false;
+  };
+  for (size_t i = 0; i < scene.shapes.size(); i++)
+    if (!load_shape(path_join(dirname, shape_uris[i]), scene.shapes[i], error, true)) return dependent_error();
+  for (size_t i = 0; i < scene.volumes.size(); i++)
+    if (!load_volume(path_join(dirname, volume_uris[i]), scene.volumes[i], volume_binary[i], error)) return dependent_error();
+  for (size_t i = 0; i < scene.textures.size(); i++)
+    if (!load_texture(path_join(dirname, texture_uris[i]), scene.textures[i], error)) return dependent_error();
+
+  // add_missing_camera is not restated: every BASELINE scene has cameras
+  if (scene.cameras.empty()) {
+    error = filename + ": no camera";
+    return false;
+  }
+  // index validation (the reference trusts the file; the device path must not)
+  auto bad = [&](int v, size_t n, bool optional) { return optional ? (v < -1 || v >= (int)n) : (v < 0 || v >= (int)n); };
+  for (auto& i : scene.instances)
+    if (bad(i.shape, scene.shapes.size(), false) || bad(i.material, scene.materials.size(), false)) return parse_error();
+  for (auto& m : scene.materials)
+    for (auto t : {m.emission_tex, m.color_tex, m.roughness_tex, m.scattering_tex, m.normal_tex}) (void)t;
+  for (auto& e : scene.environments)
+    if (bad(e.emission_tex, scene.textures.size(), true)) return parse_error();
+  for (auto& i : scene.vol_instances)
+    if (bad(i.volume, scene.volumes.size(), false) || bad(i.material, scene.materials.size(), false)) return parse_error();
+  for (auto& s : scene.sdfs)
+    if (bad(s.material, scene.materials.size(), false)) return parse_error();
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// output: linear float -> sRGB bytes (yocto_color.h:207-231), PNG writer
+// ---------------------------------------------------------------------------------------------
+vector<vec4b> linear_to_srgb8(const color_image& image) {
+  auto out   = vector<vec4b>(image.pixels.size());
+  auto curve = [](float rgb) { return (rgb <= 0.0031308f) ? 12.92f * rgb : (1 + 0.055f) * std::pow(rgb, 1 / 2.4f) - 0.055f; };
+  auto quant = [](float a) {
+    auto v = (int)(a * 256);
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+  };
+  for (size_t i = 0; i < out.size(); i++) {
+    auto& p = image.pixels[i];
+    out[i]  = {quant(curve(p.x)), quant(curve(p.y)), quant(curve(p.z)), quant(p.w)};
+  }
+  return out;
+}
+
+vector<uint8_t> encode_png(int width, int height, const vector<vec4b>& rgba) {
+  auto raw = vector<uint8_t>(((size_t)width * 4 + 1) * height);
+  for (auto y = 0; y < height; y++) {
+    raw[(size_t)y * (width * 4 + 1)] = 0;
+    memcpy(&raw[(size_t)y * (width * 4 + 1) + 1], &rgba[(size_t)y * width], (size_t)width * 4);
+  }
+  auto bound = compressBound((uLong)raw.size());
+  auto comp  = vector<uint8_t>(bound);
+  compress2(comp.data(), &bound, raw.data(), (uLong)raw.size(), 6);
+  comp.resize(bound);
+  auto out   = vector<uint8_t>{0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+  auto chunk = [&](const char* type, const vector<uint8_t>& body) {
+    auto len = (uint32_t)body.size();
+    for (auto s = 24; s >= 0; s -= 8) out.push_back((uint8_t)(len >> s));
+    auto start = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), body.begin(), body.end());
+    auto crc = (uint32_t)crc32(0, &out[start], (uInt)(out.size() - start));
+    for (auto s = 24; s >= 0; s -= 8) out.push_back((uint8_t)(crc >> s));
+  };
+  auto ihdr = vector<uint8_t>(13);
+  for (auto k = 0; k < 4; k++) ihdr[k] = (uint8_t)(width >> (24 - 8 * k)), ihdr[4 + k] = (uint8_t)(height >> (24 - 8 * k));
+  ihdr[8] = 8, ihdr[9] = 6;
+  chunk("IHDR", ihdr), chunk("IDAT", comp), chunk("IEND", {});
+  return out;
+}
+
+bool save_image(const string& filename, const color_image& image, string& error) {
+  auto ext   = path_extension(filename);
+  auto bytes = vector<uint8_t>{};
+  // save_image on a linear image converts to sRGB bytes first (yocto_sceneio.cpp:523-531, 565-571)
+  auto ldr = image.linear ? linear_to_srgb8(image) : vector<vec4b>{};
+  if (!image.linear) {
+    ldr.resize(image.pixels.size());
+    for (size_t i = 0; i < ldr.size(); i++) {
+      auto q = [](float a) { auto v = (int)(a * 256); return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+      ldr[i] = {q(image.pixels[i].x), q(image.pixels[i].y), q(image.pixels[i].z), q(image.pixels[i].w)};
+    }
+  }
+  if (ext == ".png") bytes = encode_png(image.width, image.height, ldr);
+  else if (ext == ".jpg" || ext == ".jpeg") bytes = encode_jpeg_q75(image.width, image.height, ldr);
+  else if (ext == ".raw") {  // float32 RGBA dump, for tools
+    bytes.resize(image.pixels.size() * 16);
+    memcpy(bytes.data(), image.pixels.data(), bytes.size());
+  } else {
+    error = filename + ": unknown format";
+    return false;
+  }
+  auto f = fopen(filename.c_str(), "wb");
+  if (!f || fwrite(bytes.data(), 1, bytes.size(), f) != bytes.size()) {
+    if (f) fclose(f);
+    error = filename + ": write error";
+    return false;
+  }
+  fclose(f);
+  return true;
+}
+
+}  // namespace vpt

@@ -1,0 +1,84 @@
+"""Test-side loader for the CHECKERS under oracle/ (never imported by the product):
+  * libvpt_oracle.so  — our CPU restatement (oracle/vpt_oracle.cpp), same contract as vpt_render
+  * _ref/ref_driver   — the reference's own renderer built by oracle/Makefile (only where it exists)
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libvpt_oracle.so")
+REF_DRIVER = os.path.join(ORACLE_DIR, "_ref", "ref_driver")
+COUNTER_NAMES = ("samples,scene_nodes,shape_nodes,instance_tests,quad_tests,tri_tests,texel_f32,texel_u8,"
+                 "cdf_probes,surface_hits,volume_events,bounces,sdf_evals,voxel_fetches,light_pdf_hops").split(",")
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
+        _lib = C.CDLL(ORACLE_SO)
+        _lib.vpt_oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_void_p]
+    return _lib
+
+
+def oracle_render(host_scene, params, state, nsamples, nthreads=0, counters=False):
+    """Advance `state` by `nsamples` passes with the CPU oracle. Returns a counter dict if asked."""
+    abi = params.to_abi()
+    samples = C.c_int(state.samples)
+    cnt = np.zeros(16, np.uint64)
+    rc = lib().vpt_oracle_render(host_scene.desc, C.addressof(abi), nsamples, state.width, state.height,
+                                 state.image.ctypes.data, state.hits.ctypes.data, state.rngs.ctypes.data,
+                                 C.byref(samples), nthreads, cnt.ctypes.data if counters else None)
+    if rc != 0:
+        raise RuntimeError(f"oracle failed: {rc}")
+    state.samples = samples.value
+    return dict(zip(COUNTER_NAMES, (int(x) for x in cnt))) if counters else None
+
+
+def have_reference():
+    return os.path.exists(REF_DRIVER)
+
+
+def reference_render(scene_json, shader, resolution, samples, bounces=4, stmaxiter=450, camera=0, noparallel=False,
+                     noimplicitmis=False, workdir="/tmp", stats=False, output=None):
+    """Run the reference's own renderer; returns (width, height, image, hits, rngs, info[, stats])."""
+    state_file = os.path.join(workdir, f"ref_state_{os.getpid()}.bin")
+    cmd = [REF_DRIVER, "--scene", scene_json, "--shader", shader, "--resolution", str(resolution), "--samples",
+           str(samples), "--bounces", str(bounces), "--stmaxiter", str(stmaxiter), "--camera", str(camera),
+           "--state", state_file]
+    stats_file = os.path.join(workdir, f"ref_stats_{os.getpid()}.json")
+    if stats:
+        cmd += ["--stats", stats_file]
+    if output:
+        cmd += ["--output", output]
+    if noparallel:
+        cmd.append("--noparallel")
+    if noimplicitmis:
+        cmd.append("--noimplicitmis")
+    out = subprocess.check_output(cmd)
+    info = json.loads(out.decode().strip().splitlines()[-1])
+    raw = open(state_file, "rb").read()
+    os.remove(state_file)
+    hdr = np.frombuffer(raw, np.int32, 4)
+    assert hdr[0] == 0x53545056
+    w, h, n = int(hdr[1]), int(hdr[2]), int(hdr[3])
+    off = 16
+    image = np.frombuffer(raw, np.float32, w * h * 4, off).reshape(h, w, 4).copy()
+    off += w * h * 16
+    hits = np.frombuffer(raw, np.int32, w * h, off).reshape(h, w).copy()
+    off += w * h * 4
+    rngs = np.frombuffer(raw, np.uint64, w * h * 2, off).reshape(h, w, 2).copy()
+    res = [w, h, image, hits, rngs, info]
+    if stats:
+        res.append(json.load(open(stats_file)))
+        os.remove(stats_file)
+    return res

@@ -1,0 +1,252 @@
+"""vpt-mi355x: ctypes bindings over the C-ABI of ``include/vpt.h`` (libvpt_hip.so, the HIP
+path) and over the host library (libvpt_host.so: scene.json loader, BVH / light / state builders
+that mirror ``libs/yocto_pathtrace/yocto_pathtrace.h:119-139`` of the reference).
+
+Nothing in this package computes radiance on the CPU and nothing here touches ``oracle/``: if
+the HIP library is missing or no GPU is present, rendering raises ``VptError``.
+
+The directory name contains a dash, so import it with ``vpt_loader.load()`` (repo root) or
+``importlib``; inside, everything is ordinary Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+SHADER_NAMES = ["volpathtrace", "pathtrace", "naive", "eyelight", "normal", "texcoord", "color",
+                "implicit", "implicit_normal"]  # yocto_pathtrace.h:101-103
+
+
+class VptError(RuntimeError):
+    pass
+
+
+def _lib(name: str) -> C.CDLL:
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        raise VptError(f"{path} is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+hip = _lib("libvpt_hip.so")    # must load first: libvpt_host.so links against it
+host = _lib("libvpt_host.so")
+
+
+class VptParams(C.Structure):  # vpt_params
+    _fields_ = [("camera", C.c_int32), ("resolution", C.c_int32), ("shader", C.c_int32),
+                ("samples", C.c_int32), ("bounces", C.c_int32), ("noparallel", C.c_int32),
+                ("noimplicit_mis", C.c_int32), ("spheretrace_maxiter", C.c_int32)]
+
+
+class VptLayout(C.Structure):  # vpt_layout
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("tile_w", C.c_int32),
+                ("tile_h", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32)]
+
+
+@dataclass
+class PathtraceParams:
+    """pathtrace_params, yocto_pathtrace.h:87-99 (same names, same defaults)."""
+    camera: int = 0
+    resolution: int = 720
+    shader: str = "pathtrace"
+    samples: int = 512
+    bounces: int = 4
+    noparallel: bool = False
+    noimplicit_mis: bool = False
+    spheretrace_maxiter: int = 450
+
+    def to_abi(self) -> VptParams:
+        if self.shader not in SHADER_NAMES:
+            raise VptError("sampler unknown")  # reference: get_shader throws (cpp:947-950)
+        return VptParams(self.camera, self.resolution, SHADER_NAMES.index(self.shader), self.samples,
+                         self.bounces, int(self.noparallel), int(self.noimplicit_mis),
+                         self.spheretrace_maxiter)
+
+
+@dataclass
+class PathtraceState:
+    """pathtrace_state, yocto_pathtrace.h:57-64: row-major host arrays."""
+    width: int
+    height: int
+    samples: int = 0
+    image: np.ndarray = field(default=None)  # (h, w, 4) float32 running sums
+    hits: np.ndarray = field(default=None)   # (h, w) int32
+    rngs: np.ndarray = field(default=None)   # (h, w, 2) uint64 {state, inc}
+
+    def copy(self) -> "PathtraceState":
+        return PathtraceState(self.width, self.height, self.samples, self.image.copy(), self.hits.copy(),
+                              self.rngs.copy())
+
+
+# ---- prototypes -----------------------------------------------------------------------------
+_p = C.c_void_p
+hip.vpt_last_error.restype = C.c_char_p
+hip.vpt_version.restype = C.c_char_p
+hip.vpt_device_count.restype = C.c_int
+hip.vpt_scene_create.argtypes = [_p, C.c_int, C.POINTER(_p)]
+hip.vpt_scene_destroy.argtypes = [_p]
+hip.vpt_scene_destroy.restype = None
+hip.vpt_render.argtypes = [_p, C.POINTER(VptParams), C.c_int, C.c_int, C.c_int, _p, _p, _p, C.POINTER(C.c_int)]
+hip.vpt_layout_slots.argtypes = [C.POINTER(VptLayout)]
+hip.vpt_layout_slots.restype = C.c_int64
+hip.vpt_state_upload.argtypes = [C.POINTER(VptLayout), _p, _p, _p, _p, _p, _p, _p]
+hip.vpt_state_download.argtypes = [C.POINTER(VptLayout), _p, _p, _p, _p, _p, _p, _p]
+hip.vpt_render_device.argtypes = [_p, C.POINTER(VptParams), C.POINTER(VptLayout), C.c_int, _p, _p, _p, _p]
+hip.vpt_resolve_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
+hip.vpt_last_kernel_ms.argtypes = [_p, C.POINTER(C.c_float)]
+host.vpth_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+host.vpth_scene_load.restype = _p
+host.vpth_scene_free.argtypes = [_p]
+host.vpth_scene_free.restype = None
+host.vpth_scene_desc.argtypes = [_p]
+host.vpth_scene_desc.restype = _p
+host.vpth_state_size.argtypes = [_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+host.vpth_make_state.argtypes = [_p, C.c_int, C.c_int, _p, _p, _p]
+host.vpth_scene_stats.argtypes = [_p, C.c_char_p, C.c_int]
+host.vpth_linear_to_srgb8.argtypes = [C.c_int, C.c_int, _p, C.c_int, _p]
+host.vpth_linear_to_srgb8.restype = None
+host.vpth_encode_jpeg_q75.argtypes = [C.c_int, C.c_int, _p, _p, C.c_int64]
+host.vpth_encode_jpeg_q75.restype = C.c_int64
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise VptError(f"{what} failed ({rc}): {hip.vpt_last_error().decode()}")
+
+
+def device_count() -> int:
+    return hip.vpt_device_count()
+
+
+class HostScene:
+    """load_scene + tesselate_surfaces + make_bvh + make_lights, flattened for the C-ABI."""
+
+    def __init__(self, filename: str):
+        err = C.create_string_buffer(1024)
+        self.handle = host.vpth_scene_load(os.fsencode(filename), err, len(err))
+        if not self.handle:
+            raise VptError(err.value.decode())
+        self.filename = filename
+
+    @property
+    def desc(self) -> int:
+        """address of the vpt_scene_desc (valid while this object lives)"""
+        return host.vpth_scene_desc(self.handle)
+
+    def stats(self) -> str:
+        buf = C.create_string_buffer(1 << 20)
+        n = host.vpth_scene_stats(self.handle, buf, len(buf))
+        if n < 0:
+            raise VptError("stats buffer too small")
+        return buf.value.decode()
+
+    def make_state(self, params: PathtraceParams) -> PathtraceState:
+        """make_state, yocto_pathtrace.cpp:960-980"""
+        w, h = C.c_int(), C.c_int()
+        if host.vpth_state_size(self.handle, params.camera, params.resolution, C.byref(w), C.byref(h)) != 0:
+            raise VptError("camera index out of range")
+        st = PathtraceState(w.value, h.value, 0, np.zeros((h.value, w.value, 4), np.float32),
+                            np.zeros((h.value, w.value), np.int32), np.zeros((h.value, w.value, 2), np.uint64))
+        if host.vpth_make_state(self.handle, params.camera, params.resolution, st.image.ctypes.data,
+                                st.hits.ctypes.data, st.rngs.ctypes.data) != 0:
+            raise VptError("make_state failed")
+        return st
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            host.vpth_scene_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+class DeviceScene:
+    """vpt_scene: the scene resident in one GPU's HBM."""
+
+    def __init__(self, scene: HostScene, device: int = 0):
+        self.host_scene = scene  # keep the flattened arrays alive until the upload finished
+        out = _p()
+        _check(hip.vpt_scene_create(scene.desc, device, C.byref(out)), "vpt_scene_create")
+        self.handle = out
+        self.device = device
+
+    # -- the drop-in for pathtrace_samples(): host state in, host state out ---------------------
+    def pathtrace_samples(self, state: PathtraceState, params: PathtraceParams, count: int = 1) -> None:
+        abi = params.to_abi()
+        samples = C.c_int(state.samples)
+        for a in (state.image, state.hits, state.rngs):
+            assert a.flags["C_CONTIGUOUS"]
+        _check(hip.vpt_render(self.handle, C.byref(abi), count, state.width, state.height, state.image.ctypes.data,
+                              state.hits.ctypes.data, state.rngs.ctypes.data, C.byref(samples)), "vpt_render")
+        state.samples = samples.value
+
+    # -- device-resident state (pointers are raw device addresses, e.g. torch.Tensor.data_ptr()) ----
+    def render_device(self, params: PathtraceParams, layout: VptLayout, nsamples: int, d_image: int, d_hits: int,
+                      d_rng: int, stream: int = 0) -> None:
+        abi = params.to_abi()
+        _check(hip.vpt_render_device(self.handle, C.byref(abi), C.byref(layout), nsamples, d_image, d_hits, d_rng,
+                                     stream), "vpt_render_device")
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _check(hip.vpt_last_kernel_ms(self.handle, C.byref(ms)), "vpt_last_kernel_ms")
+        return ms.value
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            hip.vpt_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+def layout_slots(layout: VptLayout) -> int:
+    n = hip.vpt_layout_slots(C.byref(layout))
+    if n < 0:
+        raise VptError(hip.vpt_last_error().decode())
+    return n
+
+
+def state_upload(layout: VptLayout, state: PathtraceState, d_image: int, d_hits: int, d_rng: int, stream: int = 0):
+    _check(hip.vpt_state_upload(C.byref(layout), state.image.ctypes.data, state.hits.ctypes.data,
+                                state.rngs.ctypes.data, d_image, d_hits, d_rng, stream), "vpt_state_upload")
+
+
+def state_download(layout: VptLayout, d_image: int, d_hits: int, d_rng: int, state: PathtraceState, stream: int = 0):
+    _check(hip.vpt_state_download(C.byref(layout), d_image, d_hits, d_rng, state.image.ctypes.data,
+                                  state.hits.ctypes.data, state.rngs.ctypes.data, stream), "vpt_state_download")
+
+
+def resolve_device(layout: VptLayout, d_tiles_all: int, samples: int, d_rows: int, stream: int = 0):
+    _check(hip.vpt_resolve_device(C.byref(layout), d_tiles_all, samples, d_rows, stream), "vpt_resolve_device")
+
+
+def get_render(state: PathtraceState) -> np.ndarray:
+    """get_render, yocto_pathtrace.cpp:1105-1116: image * (1/samples) in float32"""
+    return state.image * np.float32(np.float32(1.0) / np.float32(state.samples))
+
+
+def linear_to_srgb8(image_sum: np.ndarray, samples: int) -> np.ndarray:
+    """save_image's quantisation: rgb_to_srgb then float_to_byte (yocto_color.h:207-231)"""
+    h, w, _ = image_sum.shape
+    out = np.zeros((h, w, 4), np.uint8)
+    src = np.ascontiguousarray(image_sum, np.float32)
+    host.vpth_linear_to_srgb8(w, h, src.ctypes.data, samples, out.ctypes.data)
+    return out
+
+
+def encode_jpeg_q75(rgba8: np.ndarray) -> bytes:
+    """byte-exact stand-in for the reference's stbi_write_jpg(..., quality 75) (stb_image_write.h:1398-1611)"""
+    h, w, _ = rgba8.shape
+    src = np.ascontiguousarray(rgba8, np.uint8)
+    n = host.vpth_encode_jpeg_q75(w, h, src.ctypes.data, None, 0)
+    buf = (C.c_uint8 * n)()
+    host.vpth_encode_jpeg_q75(w, h, src.ctypes.data, buf, n)
+    return bytes(buf)

@@ -1,0 +1,85 @@
+// vpt_device.h — device-resident scene layout shared by the C-ABI host code (vpt_capi.hip)
+// and the kernels (vpt_kernels.hip.inc).  All arrays live in HBM for the life of a vpt_scene;
+// layouts are chosen for 16-byte vector loads (global_load_dwordx4) per lane:
+//
+//   bvh node      32 B  = 2 x float4   {min.xyz, max.x} {max.yz, start, num|axis<<16|internal<<24}
+//   leaf record   64 B  = 4 x float4   the 4 corner positions of one quad (a triangle repeats its
+//                                      last corner) stored IN BVH LEAF ORDER, element id in p0.w:
+//                                      a leaf's <=4 primitives are one contiguous <=256 B run, and
+//                                      the reference's prims[] -> quads[] -> positions[] double
+//                                      indirection (yocto_bvh.cpp:780-789) is gone from traversal
+//   instance     128 B  = 8 x float4   inverse frame (3x4) first: it is what traversal reads
+//   vertex attrs       float4 positions / float4 normals / float2 texcoords / float4 colors
+//   textures           uchar4 or float4 texels; sRGB->linear through a 256-entry float LUT computed
+//                      on the host with the same powf the reference calls per fetch
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vpt.h"
+
+struct DInstance {       // 128 B
+  float4 inv[3];         // inverse(frame, non_rigid=true): rows packed as x,y,z columns + o: see pack
+  float4 fwd[3];
+  int    shape, material;
+  int    pad[6];
+};
+// A frame {x,y,z,o} (4 columns of 3) packed in 3 float4: {x.x,x.y,x.z,y.x} {y.y,y.z,z.x,z.y} {z.z,o.x,o.y,o.z}
+
+struct DShape {          // 48 B
+  int num_nodes, node_offset;  // into shape_nodes (in nodes)
+  int leaf_offset;             // into leaf_prims (in records), slot = leaf_offset + node.start + k
+  int is_triangles;            // shape.triangles non-empty (reference tests triangles first)
+  int elem_offset;             // into elems (int4 per element; triangles repeat z in w)
+  int vertex_offset;           // into positions
+  int normal_offset, texcoord_offset, color_offset;  // -1 if absent
+  int num_elems;
+  int stack_need;              // max traversal stack depth for this shape's BVH
+  int pad;
+};
+
+struct DScene {
+  // counts
+  int num_cameras, num_instances, num_shapes, num_materials, num_textures, num_environments;
+  int num_volumes, num_vol_instances, num_sdfs, num_lights, num_scene_nodes, pad0;
+  // bvh
+  const float4* scene_nodes;   // 2 per node
+  const int*    scene_prims;
+  const float4* shape_nodes;   // 2 per node, pooled
+  const float4* leaf_prims;    // 4 per slot, pooled
+  // geometry
+  const DInstance* instances;
+  const DShape*    shapes;
+  const int4*      elems;
+  const float4*    positions;
+  const float4*    normals;
+  const float2*    texcoords;
+  const float4*    colors;
+  // appearance
+  const vpt_material*    materials;
+  const vpt_texture*     textures;
+  const float4*          texels_f;
+  const uchar4*          texels_b;
+  const float*           srgb_lut;      // 256 entries
+  const vpt_environment* environments;
+  const float4*          env_inv;       // 3 float4 per environment: inverse(frame) (rigid)
+  // lights
+  const vpt_light* lights;
+  const float*     light_cdf;
+  // implicit surfaces
+  const vpt_volume*          volumes;
+  const float*               voxels;
+  const vpt_volume_instance* vol_instances;
+  const vpt_sdf*             sdfs;
+  const float4*              sdf_inv;   // 3 float4 per sdf: inverse(frame) (rigid), for light sampling
+  const vpt_camera*          cameras;
+};
+
+struct DParams {
+  int   camera, shader, bounces, noimplicit_mis, spheretrace_maxiter;
+  int   preview;       // params.samples == 1 branch (yocto_pathtrace.cpp:1059-1068)
+  int   nsamples;      // passes to render in this launch
+  // layout
+  int   width, height, tile_w, tile_h, tiles_x, tiles_y, rank, nranks;
+  int   nslots;        // state slots of this rank (multiple of 64)
+};

@@ -1,0 +1,330 @@
+// vpt_kernels.hip.h — the render kernels.
+//
+// K1 vpt_render_kernel<SHADER>: one lane owns one pixel for the whole launch (all `nsamples`
+// passes), one wave64 owns one 8x8 pixel tile (64 consecutive slots of the tile-major state), a
+// 256-thread workgroup owns 4 tiles.  A lane keeps its pixel's PCG32 stream, radiance sum and hit
+// count in registers and touches HBM state exactly once per launch (coalesced 16 B/lane loads and
+// stores).  Paths are REGENERATED PER LANE: the reference's two nested loops (samples x bounces,
+// yocto_pathtrace.cpp:1081-1090 x 577-684) are flattened into one loop whose body is "one path
+// vertex", so a lane that finishes a short path starts its pixel's next sample immediately instead
+// of idling until the longest path of the wave ends.  Because a pixel's samples are still consumed
+// serially from its own stream, results are independent of how lanes interleave.
+//
+// Replaces: pathtrace_samples + shade_* (yocto_pathtrace.cpp:425-930, 1052-1092).
+#pragma once
+#include "vpt_scene.hip.h"
+
+enum { K_VOLPATH = 0, K_PATH = 1, K_NAIVE = 2, K_EYELIGHT = 3, K_DEBUG = 4, K_IMPLICIT = 5, K_IMPLICIT_NORMAL = 6 };
+
+// slot -> pixel for the tile-major layout of include/vpt.h (vpt_layout)
+VPT_DEV bool slot_to_pixel(const DParams& pr, int slot, int& px, int& py) {
+  int per_tile   = pr.tile_w * pr.tile_h;
+  int local_tile = slot / per_tile, p = slot - local_tile * per_tile;
+  int tile       = local_tile * pr.nranks + pr.rank;
+  if (tile >= pr.tiles_x * pr.tiles_y) return false;
+  int ty = tile / pr.tiles_x, tx = tile - ty * pr.tiles_x;
+  // inside a tile, pixels are ordered in 8x8 blocks so that a wave covers a square footprint
+  int bw = pr.tile_w >> 3, blk = p >> 6, q = p & 63;
+  int by = blk / bw, bx = blk - by * bw;
+  px = tx * pr.tile_w + bx * 8 + (q & 7);
+  py = ty * pr.tile_h + by * 8 + (q >> 3);
+  return px < pr.width && py < pr.height;
+}
+
+// MIS direction choice shared by the surface shaders (yocto_pathtrace.cpp:621-639, 728-746, 488-519).
+// RNG draw order is the reference's right-to-left argument evaluation.
+// Returns false when the path ends (`incoming == 0`).
+template <bool MIS_ALWAYS>
+VPT_DEV bool next_direction(const DScene& sc, const DParams& pr, const mpoint& m, f3 normal, f3 outgoing, f3 position,
+    rng_t& rng, f3& weight, f3& incoming, const lane_stack& stk) {
+  incoming = mk3(0, 0, 0);
+  if (!is_delta(m)) {
+    bool  mis  = MIS_ALWAYS || !pr.noimplicit_mis;
+    float coin = rand1f(rng);
+    if (coin < (mis ? 0.5f : 1.0f)) {
+      f2 rn;
+      rn.x      = rand1f(rng);
+      rn.y      = rand1f(rng);
+      float rnl = rand1f(rng);
+      incoming  = sample_bsdfcos(m, normal, outgoing, rnl, rn);
+    } else {
+      f2 ruv;
+      ruv.x     = rand1f(rng);
+      ruv.y     = rand1f(rng);
+      float rel = rand1f(rng);
+      float rl  = rand1f(rng);
+      incoming  = sample_lights(sc, position, rl, rel, ruv);
+    }
+    if (is_zero3(incoming)) return false;
+    f3    f   = eval_bsdfcos(m, normal, outgoing, incoming);
+    float pdf = sample_bsdfcos_pdf(m, normal, outgoing, incoming);
+    if (mis) pdf = 0.5f * pdf + 0.5f * sample_lights_pdf(sc, position, incoming, pr.spheretrace_maxiter, stk);
+    weight = weight * (f / pdf);
+  } else {
+    float rnl = rand1f(rng);
+    incoming  = sample_delta(m, normal, outgoing, rnl);
+    weight    = weight * (eval_delta(m, normal, outgoing, incoming) / sample_delta_pdf(m, normal, outgoing, incoming));
+  }
+  return true;
+}
+
+// weight test + russian roulette, yocto_pathtrace.cpp:676-683
+VPT_DEV bool survive(f3& weight, int bounce, rng_t& rng) {
+  if (is_zero3(weight) || !finite3(weight)) return false;
+  if (bounce > 3) {
+    float rr_prob = fmin_(0.99f, max3(weight));
+    if (rand1f(rng) >= rr_prob) return false;
+    weight = weight * (1 / rr_prob);
+  }
+  return true;
+}
+
+template <int SH>
+__global__ void __launch_bounds__(VPT_BLOCK) vpt_render_kernel(DScene sc, DParams pr, float4* __restrict__ image,
+    int* __restrict__ hits, ulonglong2* __restrict__ rngs, int stack_cap) {
+  extern __shared__ int lds_stack[];
+  lane_stack stk;
+  stk.base = lds_stack + threadIdx.x;
+  stk.cap  = stack_cap;
+
+  int slot = blockIdx.x * VPT_BLOCK + threadIdx.x;
+  int px = 0, py = 0;
+  if (slot >= pr.nslots || !slot_to_pixel(pr, slot, px, py)) return;   // padding lanes own no pixel
+
+  // ---- pixel state: one coalesced read, kept in registers for the whole launch ----------------
+  float4     acc_in = image[slot];
+  f4         acc    = mk4(acc_in.x, acc_in.y, acc_in.z, acc_in.w);
+  ulonglong2 r_in   = rngs[slot];
+  rng_t      rng    = {r_in.x, r_in.y};
+  const vpt_camera cam = sc.cameras[pr.camera];
+  const int nb = (SH == K_EYELIGHT) ? max(pr.bounces, 4) : pr.bounces;
+
+  // ---- path state --------------------------------------------------------------------------------
+  ray_t ray    = make_ray(mk3(0, 0, 0), mk3(0, 0, 1));
+  f3    radiance = mk3(0, 0, 0), weight = mk3(1, 1, 1);
+  float alpha  = 0;
+  int   bounce = 0, sample = 0;
+  bool  fresh  = true;
+  // 1-deep medium slot (the reference's vstack never holds more than one entry, cpp:644-647)
+  bool  in_medium = false;
+  f3    med_density = mk3(0, 0, 0), med_scattering = mk3(0, 0, 0), med_emission = mk3(0, 0, 0);
+  float med_g = 0;
+
+  while (true) {
+    if (fresh) {
+      if (sample == pr.nsamples) break;
+      float u, v;
+      if (pr.preview) {
+        u = (px + 0.5f) / pr.width, v = (py + 0.5f) / pr.height;
+      } else {
+        u = (px + rand1f(rng)) / pr.width;
+        v = (py + rand1f(rng)) / pr.height;
+      }
+      f2 lens;
+      lens.x = rand1f(rng);
+      lens.y = rand1f(rng);
+      ray    = eval_camera(cam, mk2(u, v), lens);
+      radiance = mk3(0, 0, 0), weight = mk3(1, 1, 1);
+      alpha = (SH == K_IMPLICIT) ? 1.0f : 0.0f;
+      bounce = 0, in_medium = false, fresh = false;
+    }
+
+    bool finish = false;
+    if constexpr (SH == K_DEBUG) {   // shade_normal / texcoord / color, cpp:893-930
+      hit_t h = trace_scene(sc, ray, stk);
+      if (h.hit) {
+        const DInstance& inst = sc.instances[h.instance];
+        if (pr.shader == VPT_SHADER_NORMAL) radiance = eval_shading_normal(sc, inst, h.element, h.uv, -ray.d);
+        else if (pr.shader == VPT_SHADER_TEXCOORD) {
+          f2 t = eval_texcoord(sc, inst, h.element, h.uv);
+          radiance = mk3(t.x, t.y, 0);
+        } else radiance = eval_material(sc, inst, h.element, h.uv).color;
+        alpha = 1;
+      }
+      finish = true;
+    } else if constexpr (SH == K_IMPLICIT_NORMAL) {   // cpp:538-562
+      st_hit h = spheretrace(sc, ray, pr.spheretrace_maxiter);
+      if (h.hit) {
+        f3 position = ray_point(ray, h.dist);
+        f3 n = h.instance != VPT_INVALID ? eval_sdf_normal_grid(sc, sc.vol_instances[h.instance], position, h.dist)
+                                         : eval_sdf_normal_function(sc.sdfs[h.sdf], position, h.dist);
+        radiance = n * 0.5f + 0.5f;
+        alpha    = 1;
+      }
+      finish = true;
+    } else if (bounce >= nb) {
+      finish = true;
+    } else if constexpr (SH == K_IMPLICIT) {   // shade_implicit, cpp:425-535
+      st_hit h = spheretrace(sc, ray, pr.spheretrace_maxiter);
+      if (!h.hit) {
+        radiance = radiance + weight * eval_environment(sc, ray.d);
+        finish   = true;
+      } else {
+        f3 outgoing = -ray.d;
+        f3 position = ray_point(ray, h.dist);
+        f3 normal   = h.instance != VPT_INVALID ? eval_sdf_normal_grid(sc, sc.vol_instances[h.instance], position, h.dist)
+                                                : eval_sdf_normal_function(sc.sdfs[h.sdf], position, h.dist);
+        int    mat  = h.instance != VPT_INVALID ? sc.vol_instances[h.instance].material : sc.sdfs[h.sdf].material;
+        mpoint m    = eval_material_plain(sc, mat);
+        if (m.opacity < 1 && rand1f(rng) >= m.opacity) {
+          ray = make_ray(position + ray.d * 1e-2f, ray.d);   // bounce -= 1; continue
+        } else {
+          radiance = radiance + weight * eval_emission(m.emission, normal, outgoing);
+          f3 incoming;
+          if (!next_direction<false>(sc, pr, m, normal, outgoing, position, rng, weight, incoming, stk)) finish = true;
+          else {
+            ray = make_ray(position, incoming);
+            if (!survive(weight, bounce, rng)) finish = true;
+            bounce++;
+          }
+        }
+      }
+    } else {   // surface shaders over the two-level BVH
+      hit_t h = trace_scene(sc, ray, stk);
+      if (!h.hit) {
+        radiance = radiance + weight * eval_environment(sc, ray.d);
+        finish   = true;
+      } else {
+        bool in_volume = false;
+        if constexpr (SH == K_VOLPATH) {
+          if (in_medium) {   // cpp:586-596 — rd is drawn before rl
+            float rd       = rand1f(rng);
+            float rl       = rand1f(rng);
+            float distance = sample_transmittance(med_density, h.distance, rl, rd);
+            weight = weight * (vexp3(-med_density * distance) / sample_transmittance_pdf(med_density, distance, h.distance));
+            in_volume  = distance < h.distance;
+            h.distance = distance;
+          }
+        }
+        if (!in_volume) {
+          const DInstance& inst = sc.instances[h.instance];
+          f3     outgoing = -ray.d;
+          f3     position = eval_position(sc, inst, h.element, h.uv);
+          f3     normal   = eval_shading_normal(sc, inst, h.element, h.uv, outgoing);
+          mpoint m        = eval_material(sc, inst, h.element, h.uv);
+          if (m.opacity < 1 && rand1f(rng) >= m.opacity) {
+            ray = make_ray(position + ray.d * 1e-2f, ray.d);   // bounce -= 1; continue
+          } else {
+            if (bounce == 0) alpha = 1;
+            radiance = radiance + weight * eval_emission(m.emission, normal, outgoing);
+            f3 incoming = mk3(0, 0, 0);
+            if constexpr (SH == K_EYELIGHT) {   // cpp:869-886
+              incoming = outgoing;
+              radiance = radiance + weight * VPT_PI * eval_bsdfcos(m, normal, outgoing, incoming);
+              if (!is_delta(m)) finish = true;
+              else {
+                incoming = sample_delta(m, normal, outgoing, rand1f(rng));
+                if (is_zero3(incoming)) finish = true;
+                else {
+                  weight = weight * (eval_delta(m, normal, outgoing, incoming) / sample_delta_pdf(m, normal, outgoing, incoming));
+                  if (is_zero3(weight) || !finite3(weight)) finish = true;
+                  else ray = make_ray(position, incoming);
+                }
+              }
+              bounce++;
+            } else if constexpr (SH == K_NAIVE) {   // cpp:802-828
+              if (m.roughness != 0) {
+                f2 rn;
+                rn.x      = rand1f(rng);
+                rn.y      = rand1f(rng);
+                float rnl = rand1f(rng);
+                incoming  = sample_bsdfcos(m, normal, outgoing, rnl, rn);
+                if (is_zero3(incoming)) finish = true;
+                else weight = weight * (eval_bsdfcos(m, normal, outgoing, incoming) / sample_bsdfcos_pdf(m, normal, outgoing, incoming));
+              } else {
+                incoming = sample_delta(m, normal, outgoing, rand1f(rng));
+                if (is_zero3(incoming)) finish = true;
+                else weight = weight * (eval_delta(m, normal, outgoing, incoming) / sample_delta_pdf(m, normal, outgoing, incoming));
+              }
+              if (!finish) {
+                if (!survive(weight, bounce, rng)) finish = true;
+                else ray = make_ray(position, incoming);
+              }
+              bounce++;
+            } else {   // pathtrace / volpathtrace
+              if (!next_direction<true>(sc, pr, m, normal, outgoing, position, rng, weight, incoming, stk)) finish = true;
+              else {
+                if constexpr (SH == K_VOLPATH) {   // cpp:641-648
+                  if (is_volumetric_type(sc.materials[inst.material].type) && dot(normal, outgoing) * dot(normal, incoming) < 0) {
+                    if (!in_medium) {
+                      in_medium   = true;
+                      med_density = m.density, med_scattering = m.scattering, med_emission = m.emission, med_g = m.scanisotropy;
+                    } else {
+                      in_medium = false;
+                    }
+                  }
+                }
+                ray = make_ray(position, incoming);
+                if (!survive(weight, bounce, rng)) finish = true;
+                bounce++;
+              }
+            }
+          }
+        } else {   // volume event, cpp:654-673
+          f3 outgoing = -ray.d;
+          f3 position = ray_point(ray, h.distance);
+          radiance = radiance + weight * eval_emission(med_emission, position, outgoing);   // (sic) cpp:660
+          f3 incoming;
+          if (rand1f(rng) < 0.5f) {
+            f2 rn;
+            rn.x = rand1f(rng);
+            rn.y = rand1f(rng);
+            (void)rand1f(rng);   // rnl is drawn and ignored, cpp:665
+            incoming = sample_phasefunction(med_g, outgoing, rn);
+          } else {
+            f2 ruv;
+            ruv.x     = rand1f(rng);
+            ruv.y     = rand1f(rng);
+            float rel = rand1f(rng);
+            float rl  = rand1f(rng);
+            incoming  = sample_lights(sc, position, rl, rel, ruv);
+          }
+          f3 f = med_density * med_scattering * eval_phasefunction(med_g, incoming, outgoing);
+          float pdf = 0.5f * eval_phasefunction(med_g, outgoing, incoming) +
+                      0.5f * sample_lights_pdf(sc, position, incoming, pr.spheretrace_maxiter, stk);
+          weight = weight * (f / pdf);
+          ray    = make_ray(position, incoming);
+          if (!survive(weight, bounce, rng)) finish = true;
+          bounce++;
+        }
+      }
+    }
+
+    if (finish) {   // cpp:1087-1089
+      f4 rad = mk4(radiance.x, radiance.y, radiance.z, alpha);
+      if (!(isfinite(rad.x) && isfinite(rad.y) && isfinite(rad.z) && isfinite(rad.w))) rad = mk4(0, 0, 0, 0);
+      acc = acc + rad;
+      sample++;
+      fresh = true;
+    }
+  }
+
+  image[slot] = make_float4(acc.x, acc.y, acc.z, acc.w);
+  hits[slot] += pr.nsamples;
+  ulonglong2 r_out;
+  r_out.x = rng.state, r_out.y = rng.inc;
+  rngs[slot] = r_out;
+}
+
+// ---- state layout conversion and output resolve ---------------------------------------------
+// row-major host-order arrays <-> this rank's tile-major slots (vpt_state_upload / _download)
+__global__ void vpt_permute_kernel(DParams pr, int to_tiles, float4* tiles_image, int* tiles_hits, ulonglong2* tiles_rng,
+    float4* rows_image, int* rows_hits, ulonglong2* rows_rng) {
+  int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  int px, py;
+  if (slot >= pr.nslots || !slot_to_pixel(pr, slot, px, py)) return;
+  long long idx = (long long)py * pr.width + px;
+  if (to_tiles) tiles_image[slot] = rows_image[idx], tiles_hits[slot] = rows_hits[idx], tiles_rng[slot] = rows_rng[idx];
+  else rows_image[idx] = tiles_image[slot], rows_hits[idx] = tiles_hits[slot], rows_rng[idx] = tiles_rng[slot];
+}
+// get_render (cpp:1105-1116) over the gathered buffers of all ranks: [nranks][nslots] -> row-major * 1/samples
+__global__ void vpt_resolve_kernel(DParams pr, const float4* tiles_all, float scale, float4* rows_image) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;   // global slot over all ranks
+  if (g >= pr.nslots * pr.nranks) return;
+  DParams q = pr;
+  q.rank    = g / pr.nslots;
+  int px, py;
+  if (!slot_to_pixel(q, g - q.rank * pr.nslots, px, py)) return;
+  float4 v = tiles_all[g];
+  rows_image[(long long)py * pr.width + px] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+}

@@ -1,0 +1,129 @@
+// vpt_math.hip.h — float32 vector math for the gfx950 kernels.
+//
+// Numerical contract: the kernels must take the same branch as the
+// reference CPU renderer on (almost) every random draw, so every expression keeps the
+// reference's association order (yocto_math.h), min/max/abs are the NaN-asymmetric ternary forms
+// (yocto_math.h:1354-1356), divisions stay divisions (hipcc's default correctly-rounded f32
+// div/sqrt), and the translation unit is built with -ffp-contract=off (no FMA fusion).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define VPT_DEV __device__ __forceinline__
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+struct m33 { f3 x, y, z; };
+struct frame { f3 x, y, z, o; };
+
+#define VPT_PI 3.14159274101257324f        /* (float)3.14159265358979323846 */
+#define VPT_FLT_MAX 3.402823466e+38f
+#define VPT_FLT_EPS 1.1920928955078125e-07f
+#define VPT_RAY_EPS 1e-4f
+
+VPT_DEV float fmin_(float a, float b) { return (a < b) ? a : b; }
+VPT_DEV float fmax_(float a, float b) { return (a > b) ? a : b; }
+VPT_DEV float fabs_(float a) { return a < 0 ? -a : a; }
+VPT_DEV float clampf(float a, float lo, float hi) { return fmin_(fmax_(a, lo), hi); }
+VPT_DEV int   clampi(int a, int lo, int hi) { int m = a > lo ? a : lo; return m < hi ? m : hi; }
+
+VPT_DEV f3 mk3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+VPT_DEV f2 mk2(float x, float y) { f2 r = {x, y}; return r; }
+VPT_DEV f4 mk4(float x, float y, float z, float w) { f4 r = {x, y, z, w}; return r; }
+VPT_DEV f3 xyz(float4 a) { return mk3(a.x, a.y, a.z); }
+VPT_DEV f3 xyz(f4 a) { return mk3(a.x, a.y, a.z); }
+
+VPT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+VPT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+VPT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+VPT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+VPT_DEV f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+VPT_DEV f3 operator+(f3 a, float b) { return mk3(a.x + b, a.y + b, a.z + b); }
+VPT_DEV f3 operator-(f3 a, float b) { return mk3(a.x - b, a.y - b, a.z - b); }
+VPT_DEV f3 operator*(f3 a, float b) { return mk3(a.x * b, a.y * b, a.z * b); }
+VPT_DEV f3 operator/(f3 a, float b) { return mk3(a.x / b, a.y / b, a.z / b); }
+VPT_DEV f3 operator+(float a, f3 b) { return mk3(a + b.x, a + b.y, a + b.z); }
+VPT_DEV f3 operator-(float a, f3 b) { return mk3(a - b.x, a - b.y, a - b.z); }
+VPT_DEV f3 operator*(float a, f3 b) { return mk3(a * b.x, a * b.y, a * b.z); }
+VPT_DEV bool eq3(f3 a, f3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+VPT_DEV bool is_zero3(f3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
+VPT_DEV f2 operator+(f2 a, f2 b) { return mk2(a.x + b.x, a.y + b.y); }
+VPT_DEV f2 operator-(f2 a, f2 b) { return mk2(a.x - b.x, a.y - b.y); }
+VPT_DEV f2 operator*(f2 a, float b) { return mk2(a.x * b, a.y * b); }
+VPT_DEV f2 operator-(float a, f2 b) { return mk2(a - b.x, a - b.y); }
+VPT_DEV f4 operator+(f4 a, f4 b) { return mk4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+VPT_DEV f4 operator*(f4 a, float b) { return mk4(a.x * b, a.y * b, a.z * b, a.w * b); }
+
+VPT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+VPT_DEV float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
+VPT_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+VPT_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
+VPT_DEV float length(f2 a) { return sqrtf(dot(a, a)); }
+VPT_DEV f3 normalize(f3 a) { float l = length(a); return (l != 0) ? a / l : a; }
+VPT_DEV float distance_squared(f3 a, f3 b) { return dot(a - b, a - b); }
+VPT_DEV f3 orthonormalize(f3 a, f3 b) { return normalize(a - b * dot(a, b)); }
+VPT_DEV f3 reflect(f3 w, f3 n) { return -w + 2 * dot(n, w) * n; }
+VPT_DEV f3 refract(f3 w, f3 n, float inv_eta) {
+  float cosine = dot(n, w);
+  float k      = 1 + inv_eta * inv_eta * (cosine * cosine - 1);
+  if (k < 0) return mk3(0, 0, 0);
+  return -w * inv_eta + (inv_eta * cosine - sqrtf(k)) * n;
+}
+VPT_DEV f3 vmaxs(f3 a, float b) { return mk3(fmax_(a.x, b), fmax_(a.y, b), fmax_(a.z, b)); }
+VPT_DEV f3 vmin3(f3 a, f3 b) { return mk3(fmin_(a.x, b.x), fmin_(a.y, b.y), fmin_(a.z, b.z)); }
+VPT_DEV f3 vmax3(f3 a, f3 b) { return mk3(fmax_(a.x, b.x), fmax_(a.y, b.y), fmax_(a.z, b.z)); }
+VPT_DEV f3 vclamp(f3 a, float lo, float hi) { return mk3(clampf(a.x, lo, hi), clampf(a.y, lo, hi), clampf(a.z, lo, hi)); }
+VPT_DEV f3 vabs(f3 a) { return mk3(fabs_(a.x), fabs_(a.y), fabs_(a.z)); }
+VPT_DEV f3 vsqrt(f3 a) { return mk3(sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)); }
+VPT_DEV float max3(f3 a) { return fmax_(fmax_(a.x, a.y), a.z); }
+VPT_DEV float min3(f3 a) { return fmin_(fmin_(a.x, a.y), a.z); }
+VPT_DEV float sum3(f3 a) { return a.x + a.y + a.z; }
+VPT_DEV float mean3(f3 a) { return sum3(a) / 3; }
+VPT_DEV bool finite3(f3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
+VPT_DEV f3 lerp3(f3 a, f3 b, float u) { return a * (1 - u) + b * u; }
+VPT_DEV float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+VPT_DEV f3 mul(m33 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+VPT_DEV f3 transform_point(const frame& a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.o; }
+VPT_DEV f3 transform_vector(const frame& a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+VPT_DEV f3 transform_direction(const frame& a, f3 b) { return normalize(transform_vector(a, b)); }
+VPT_DEV f3 transform_direction(m33 a, f3 b) { return normalize(mul(a, b)); }
+
+// basis_fromz, yocto_math.h:2811-2820
+VPT_DEV m33 basis_fromz(f3 v) {
+  f3    z    = normalize(v);
+  float sign = copysignf(1.0f, z.z);
+  float a    = -1.0f / (sign + z.z);
+  float b    = z.x * z.y * a;
+  m33   r;
+  r.x = mk3(1.0f + sign * z.x * z.x * a, sign * b, -sign * z.x);
+  r.y = mk3(b, sign + z.y * z.y * a, -z.y);
+  r.z = z;
+  return r;
+}
+
+// frames packed in 3 float4 (see vpt_device.h)
+VPT_DEV frame unpack_frame(float4 a, float4 b, float4 c) {
+  frame f;
+  f.x = mk3(a.x, a.y, a.z), f.y = mk3(a.w, b.x, b.y), f.z = mk3(b.z, b.w, c.x), f.o = mk3(c.y, c.z, c.w);
+  return f;
+}
+VPT_DEV frame load_frame(const float4* p) { return unpack_frame(p[0], p[1], p[2]); }
+VPT_DEV frame load_frame(const vpt_frame& v) {
+  frame f;
+  f.x = mk3(v.x[0], v.x[1], v.x[2]), f.y = mk3(v.y[0], v.y[1], v.y[2]);
+  f.z = mk3(v.z[0], v.z[1], v.z[2]), f.o = mk3(v.o[0], v.o[1], v.o[2]);
+  return f;
+}
+VPT_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+// PCG32, yocto_sampling.h:184-216 — bit-exact integer arithmetic
+struct rng_t { unsigned long long state, inc; };
+VPT_DEV unsigned int advance_rng(rng_t& rng) {
+  unsigned long long old = rng.state;
+  rng.state              = old * 6364136223846793005ULL + rng.inc;
+  unsigned int xs        = (unsigned int)(((old >> 18u) ^ old) >> 27u);
+  unsigned int rot       = (unsigned int)(old >> 59u);
+  return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+}
+VPT_DEV float rand1f(rng_t& rng) { return __uint_as_float((advance_rng(rng) >> 9) | 0x3f800000u) - 1.0f; }

@@ -1,0 +1,1009 @@
+// vpt_scene.hip.h — device functions: two-level BVH traversal with LDS stacks, primitive tests,
+// scene/material/texture/environment evaluation, BSDF lobes, media, light sampling, SDF sphere
+// tracing.  Each function names the reference lines whose arithmetic it reproduces
+// (libs/yocto/*.h|cpp, libs/yocto_pathtrace/yocto_pathtrace.cpp).
+#pragma once
+#include "vpt_device.h"
+#include "vpt_math.hip.h"
+
+#define VPT_BLOCK 256   // threads per workgroup: 4 wave64, one 8x8 pixel tile per wave
+
+// ------------------------------------------------------------------------------------------------
+// per-lane traversal stack in LDS: entry e of lane t lives at lds[e * VPT_BLOCK + t], so the 64
+// lanes of a wave touch 64 consecutive dwords (conflict-free ds_read_b32 / ds_write_b32).
+// ------------------------------------------------------------------------------------------------
+struct lane_stack {
+  int* base;   // &lds[threadIdx.x]
+  int  cap;
+  VPT_DEV void push(int& sp, int v) const {
+    if (sp < cap) base[sp * VPT_BLOCK] = v;   // capacity is sized on the host from the BVH depth
+    sp++;
+  }
+  VPT_DEV int pop(int& sp) const {
+    sp--;
+    return sp < cap ? base[sp * VPT_BLOCK] : 0;
+  }
+};
+
+struct ray_t { f3 o, d; float tmin, tmax; };
+VPT_DEV ray_t make_ray(f3 o, f3 d) { ray_t r = {o, d, VPT_RAY_EPS, VPT_FLT_MAX}; return r; }
+VPT_DEV f3 ray_point(const ray_t& r, float t) { return r.o + r.d * t; }
+
+struct hit_t { int instance, element; f2 uv; float distance; bool hit; };
+
+// intersect_triangle, yocto_geometry.h:786-819 (Moller-Trumbore, no epsilon)
+VPT_DEV bool intersect_triangle(f3 ro, f3 rd, float tmin, float tmax, f3 p0, f3 p1, f3 p2, f2& uv, float& dist) {
+  f3    edge1 = p1 - p0, edge2 = p2 - p0;
+  f3    pvec  = cross(rd, edge2);
+  float det   = dot(edge1, pvec);
+  if (det == 0) return false;
+  float inv_det = 1.0f / det;
+  f3    tvec    = ro - p0;
+  float u       = dot(tvec, pvec) * inv_det;
+  if (u < 0 || u > 1) return false;
+  f3    qvec = cross(tvec, edge1);
+  float v    = dot(rd, qvec) * inv_det;
+  if (v < 0 || u + v > 1) return false;
+  float t = dot(edge2, qvec) * inv_det;
+  if (t < tmin || t > tmax) return false;
+  uv = mk2(u, v), dist = t;
+  return true;
+}
+// intersect_quad, yocto_geometry.h:822-839
+VPT_DEV bool intersect_quad(f3 ro, f3 rd, float tmin, float tmax, f3 p0, f3 p1, f3 p2, f3 p3, f2& uv, float& dist) {
+  if (eq3(p2, p3)) return intersect_triangle(ro, rd, tmin, tmax, p0, p1, p3, uv, dist);
+  bool hit = false;
+  if (intersect_triangle(ro, rd, tmin, tmax, p0, p1, p3, uv, dist)) hit = true, tmax = dist;
+  if (intersect_triangle(ro, rd, tmin, tmax, p2, p3, p1, uv, dist)) hit = true, uv = 1 - uv, tmax = dist;
+  return hit;
+}
+// intersect_bbox(ray, dinv, bbox), yocto_geometry.h:858-868
+VPT_DEV bool intersect_bbox(f3 ro, f3 dinv, float tmin_, float tmax_, f3 bmin, f3 bmax) {
+  f3    it_min = (bmin - ro) * dinv;
+  f3    it_max = (bmax - ro) * dinv;
+  f3    lo = vmin3(it_min, it_max), hi = vmax3(it_min, it_max);
+  float t0 = fmax_(max3(lo), tmin_);
+  float t1 = fmin_(min3(hi), tmax_);
+  t1 *= 1.00000024f;
+  return t0 <= t1;
+}
+
+// shape-level traversal, yocto_bvh.cpp:699-797.  `sp0` is the stack level owned by the caller.
+VPT_DEV bool trace_shape(const DScene& sc, const DShape& sh, f3 ro, f3 rd, float tmin, float tmax,
+    const lane_stack& stk, int sp0, int& element, f2& uv, float& distance) {
+  if (sh.num_nodes == 0) return false;
+  const float4* nodes = sc.shape_nodes + 2 * (long long)sh.node_offset;
+  const float4* leafs = sc.leaf_prims + 4 * (long long)sh.leaf_offset;
+  f3  dinv = mk3(1 / rd.x, 1 / rd.y, 1 / rd.z);
+  int sgn  = (dinv.x < 0 ? 1 : 0) | (dinv.y < 0 ? 2 : 0) | (dinv.z < 0 ? 4 : 0);
+  int sp   = sp0;
+  stk.push(sp, 0);
+  bool hit = false;
+  while (sp != sp0) {
+    int    n  = stk.pop(sp);
+    float4 n0 = nodes[2 * n], n1 = nodes[2 * n + 1];
+    if (!intersect_bbox(ro, dinv, tmin, tmax, mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y))) continue;
+    int start = __float_as_int(n1.z), meta = __float_as_int(n1.w);
+    if (meta >> 24) {   // internal: near child on top (yocto_bvh.cpp:744-750)
+      int axis = (meta >> 16) & 0xff;
+      if ((sgn >> axis) & 1) stk.push(sp, start), stk.push(sp, start + 1);
+      else stk.push(sp, start + 1), stk.push(sp, start);
+    } else {
+      int num = meta & 0xffff;
+      for (int k = 0; k < num; k++) {
+        const float4* rec = leafs + 4 * (long long)(start + k);
+        float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        if (intersect_quad(ro, rd, tmin, tmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), uv, distance))
+          hit = true, element = __float_as_int(r0.w), tmax = distance;
+      }
+    }
+  }
+  return hit;
+}
+
+// transform_ray(inverse(frame, true), ray) with the inverse precomputed at scene creation
+VPT_DEV void to_instance_space(const DInstance& inst, f3 ro, f3 rd, f3& lo, f3& ld) {
+  frame inv = unpack_frame(inst.inv[0], inst.inv[1], inst.inv[2]);
+  lo = transform_point(inv, ro), ld = transform_vector(inv, rd);
+}
+
+// scene-level traversal, yocto_bvh.cpp:800-871
+VPT_DEV hit_t trace_scene(const DScene& sc, const ray_t& ray, const lane_stack& stk) {
+  hit_t r;
+  r.instance = -1, r.element = -1, r.uv = mk2(0, 0), r.distance = 0, r.hit = false;
+  if (sc.num_scene_nodes == 0) return r;
+  f3    ro = ray.o, rd = ray.d;
+  float tmin = ray.tmin, tmax = ray.tmax;
+  f3    dinv = mk3(1 / rd.x, 1 / rd.y, 1 / rd.z);
+  int   sgn  = (dinv.x < 0 ? 1 : 0) | (dinv.y < 0 ? 2 : 0) | (dinv.z < 0 ? 4 : 0);
+  int   sp   = 0;
+  stk.push(sp, 0);
+  while (sp != 0) {
+    int    n  = stk.pop(sp);
+    float4 n0 = sc.scene_nodes[2 * n], n1 = sc.scene_nodes[2 * n + 1];
+    if (!intersect_bbox(ro, dinv, tmin, tmax, mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y))) continue;
+    int start = __float_as_int(n1.z), meta = __float_as_int(n1.w);
+    if (meta >> 24) {
+      int axis = (meta >> 16) & 0xff;
+      if ((sgn >> axis) & 1) stk.push(sp, start), stk.push(sp, start + 1);
+      else stk.push(sp, start + 1), stk.push(sp, start);
+    } else {
+      int num = meta & 0xffff;
+      for (int k = 0; k < num; k++) {
+        int              id   = sc.scene_prims[start + k];
+        const DInstance& inst = sc.instances[id];
+        f3 lo, ld;
+        to_instance_space(inst, ro, rd, lo, ld);
+        if (trace_shape(sc, sc.shapes[inst.shape], lo, ld, tmin, tmax, stk, sp, r.element, r.uv, r.distance))
+          r.hit = true, r.instance = id, tmax = r.distance;
+      }
+    }
+  }
+  return r;
+}
+// single-instance query used by the light pdf, yocto_bvh.cpp:874-881
+VPT_DEV hit_t trace_instance(const DScene& sc, int instance, f3 o, f3 d, const lane_stack& stk) {
+  hit_t r;
+  r.instance = instance, r.element = -1, r.uv = mk2(0, 0), r.distance = 0;
+  const DInstance& inst = sc.instances[instance];
+  f3 lo, ld;
+  to_instance_space(inst, o, d, lo, ld);
+  r.hit = trace_shape(sc, sc.shapes[inst.shape], lo, ld, VPT_RAY_EPS, VPT_FLT_MAX, stk, 0, r.element, r.uv, r.distance);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// textures, yocto_scene.cpp:112-169 ; sRGB decode through the host-built LUT (yocto_color.h:224-227)
+// ------------------------------------------------------------------------------------------------
+VPT_DEV f4 lookup_texture(const DScene& sc, const vpt_texture& t, int i, int j, bool as_linear) {
+  long long idx = t.offset + (long long)j * t.width + i;
+  if (t.is_float) {
+    float4 v = sc.texels_f[idx];
+    return mk4(v.x, v.y, v.z, v.w);   // linear textures are returned untouched
+  }
+  uchar4 b = sc.texels_b[idx];
+  if (as_linear && !t.linear) return mk4(sc.srgb_lut[b.x], sc.srgb_lut[b.y], sc.srgb_lut[b.z], b.w / 255.0f);
+  return mk4(b.x / 255.0f, b.y / 255.0f, b.z / 255.0f, b.w / 255.0f);
+}
+VPT_DEV f4 eval_texture(const DScene& sc, int texture, f2 uv, bool as_linear) {
+  if (texture == VPT_INVALID) return mk4(1, 1, 1, 1);
+  vpt_texture t = sc.textures[texture];
+  if (t.width == 0 || t.height == 0) return mk4(0, 0, 0, 0);
+  float s = fmodf(uv.x, 1.0f) * t.width;
+  if (s < 0) s += t.width;
+  float tt = fmodf(uv.y, 1.0f) * t.height;
+  if (tt < 0) tt += t.height;
+  int   i = clampi((int)s, 0, t.width - 1), j = clampi((int)tt, 0, t.height - 1);
+  int   ii = (i + 1) % t.width, jj = (j + 1) % t.height;
+  float u = s - i, v = tt - j;
+  return lookup_texture(sc, t, i, j, as_linear) * (1 - u) * (1 - v) + lookup_texture(sc, t, i, jj, as_linear) * (1 - u) * v +
+         lookup_texture(sc, t, ii, j, as_linear) * u * (1 - v) + lookup_texture(sc, t, ii, jj, as_linear) * u * v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shape evaluation, yocto_scene.cpp:279-526 / yocto_geometry.h:506-542
+// ------------------------------------------------------------------------------------------------
+VPT_DEV f3 tri_lerp(f3 p0, f3 p1, f3 p2, f2 uv) { return p0 * (1 - uv.x - uv.y) + p1 * uv.x + p2 * uv.y; }
+VPT_DEV f2 tri_lerp(f2 p0, f2 p1, f2 p2, f2 uv) { return p0 * (1 - uv.x - uv.y) + p1 * uv.x + p2 * uv.y; }
+VPT_DEV f4 tri_lerp(f4 p0, f4 p1, f4 p2, f2 uv) { return p0 * (1 - uv.x - uv.y) + p1 * uv.x + p2 * uv.y; }
+
+// Corner selection of interpolate_triangle / interpolate_quad folded into one index shuffle:
+// triangles: (x,y,z; uv) — quads: uv.x+uv.y<=1 ? (x,y,w; uv) : (z,w,y; 1-uv)
+struct corners_t { int a, b, c; f2 uv; };
+VPT_DEV corners_t pick_corners(const DShape& sh, int4 e, f2 uv) {
+  corners_t r;
+  if (sh.is_triangles) r.a = e.x, r.b = e.y, r.c = e.z, r.uv = uv;
+  else if (uv.x + uv.y <= 1) r.a = e.x, r.b = e.y, r.c = e.w, r.uv = uv;
+  else r.a = e.z, r.b = e.w, r.c = e.y, r.uv = 1 - uv;
+  return r;
+}
+VPT_DEV f3 triangle_normal(f3 p0, f3 p1, f3 p2) { return normalize(cross(p1 - p0, p2 - p0)); }
+
+struct surf_t {   // everything the shaders need at a surface hit
+  f3 position, normal;
+  f2 texcoord;
+  f4 color_shp;
+};
+
+VPT_DEV f3 eval_position(const DScene& sc, const DInstance& inst, int element, f2 uv) {
+  const DShape& sh  = sc.shapes[inst.shape];
+  int4          e   = sc.elems[sh.elem_offset + element];
+  corners_t     c   = pick_corners(sh, e, uv);
+  const float4* pos = sc.positions + sh.vertex_offset;
+  f3 p = tri_lerp(xyz(pos[c.a]), xyz(pos[c.b]), xyz(pos[c.c]), c.uv);
+  return transform_point(unpack_frame(inst.fwd[0], inst.fwd[1], inst.fwd[2]), p);
+}
+// eval_element_normal, yocto_scene.cpp:305-327 (transform_normal with a rigid frame = direction)
+VPT_DEV f3 eval_element_normal(const DScene& sc, const DInstance& inst, int element) {
+  const DShape& sh  = sc.shapes[inst.shape];
+  int4          e   = sc.elems[sh.elem_offset + element];
+  const float4* pos = sc.positions + sh.vertex_offset;
+  f3 n;
+  if (sh.is_triangles) {
+    n = triangle_normal(xyz(pos[e.x]), xyz(pos[e.y]), xyz(pos[e.z]));
+  } else {
+    f3 p0 = xyz(pos[e.x]), p1 = xyz(pos[e.y]), p2 = xyz(pos[e.z]), p3 = xyz(pos[e.w]);
+    n = normalize(triangle_normal(p0, p1, p3) + triangle_normal(p2, p3, p1));
+  }
+  return transform_direction(unpack_frame(inst.fwd[0], inst.fwd[1], inst.fwd[2]), n);
+}
+VPT_DEV f3 eval_normal(const DScene& sc, const DInstance& inst, int element, f2 uv) {
+  const DShape& sh = sc.shapes[inst.shape];
+  if (sh.normal_offset < 0) return eval_element_normal(sc, inst, element);
+  int4          e   = sc.elems[sh.elem_offset + element];
+  corners_t     c   = pick_corners(sh, e, uv);
+  const float4* nrm = sc.normals + sh.normal_offset;
+  f3 n = normalize(tri_lerp(xyz(nrm[c.a]), xyz(nrm[c.b]), xyz(nrm[c.c]), c.uv));
+  return transform_direction(unpack_frame(inst.fwd[0], inst.fwd[1], inst.fwd[2]), n);
+}
+VPT_DEV f2 eval_texcoord(const DScene& sc, const DInstance& inst, int element, f2 uv) {
+  const DShape& sh = sc.shapes[inst.shape];
+  if (sh.texcoord_offset < 0) return uv;
+  int4          e  = sc.elems[sh.elem_offset + element];
+  corners_t     c  = pick_corners(sh, e, uv);
+  const float2* tc = sc.texcoords + sh.texcoord_offset;
+  float2 a = tc[c.a], b = tc[c.b], d = tc[c.c];
+  return tri_lerp(mk2(a.x, a.y), mk2(b.x, b.y), mk2(d.x, d.y), c.uv);
+}
+VPT_DEV f4 eval_color(const DScene& sc, const DInstance& inst, int element, f2 uv) {
+  const DShape& sh = sc.shapes[inst.shape];
+  if (sh.color_offset < 0) return mk4(1, 1, 1, 1);
+  int4          e   = sc.elems[sh.elem_offset + element];
+  corners_t     c   = pick_corners(sh, e, uv);
+  const float4* col = sc.colors + sh.color_offset;
+  float4 a = col[c.a], b = col[c.b], d = col[c.c];
+  return tri_lerp(mk4(a.x, a.y, a.z, a.w), mk4(b.x, b.y, b.z, b.w), mk4(d.x, d.y, d.z, d.w), c.uv);
+}
+// normal mapping, yocto_scene.cpp:414-457 + yocto_geometry.h:606-640 (cold: only `normal_tex` materials)
+__device__ __noinline__ f3 eval_normalmap(const DScene& sc, const DInstance& inst, int element, f2 uv, f3 normal, int normal_tex) {
+  const DShape& sh = sc.shapes[inst.shape];
+  f2 texcoord  = eval_texcoord(sc, inst, element, uv);
+  f3 normalmap = -1 + 2 * xyz(eval_texture(sc, normal_tex, texcoord, false));
+  f3 tu = mk3(0, 0, 0), tv = mk3(0, 0, 0);
+  if (sh.texcoord_offset >= 0) {
+    int4          e   = sc.elems[sh.elem_offset + element];
+    const float4* pos = sc.positions + sh.vertex_offset;
+    const float2* tc  = sc.texcoords + sh.texcoord_offset;
+    int ia = e.x, ib = e.y, ic = sh.is_triangles ? e.z : e.w;   // quads: always the (p0,p1,p3) half
+    f3 p0 = xyz(pos[ia]), p = xyz(pos[ib]) - p0, q = xyz(pos[ic]) - p0;
+    float2 t0 = tc[ia], t1 = tc[ib], t2 = tc[ic];
+    float sx = t1.x - t0.x, sy = t2.x - t0.x, tx = t1.y - t0.y, ty = t2.y - t0.y;
+    float div = sx * ty - sy * tx;
+    if (div != 0) {
+      tu = mk3(ty * p.x - tx * q.x, ty * p.y - tx * q.y, ty * p.z - tx * q.z) / div;
+      tv = mk3(sx * q.x - sy * p.x, sx * q.y - sy * p.y, sx * q.z - sy * p.z) / div;
+    } else {
+      tu = mk3(1, 0, 0), tv = mk3(0, 1, 0);
+    }
+    frame f = unpack_frame(inst.fwd[0], inst.fwd[1], inst.fwd[2]);
+    tu = transform_direction(f, tu), tv = transform_direction(f, tv);
+  }
+  f3 fx = orthonormalize(tu, normal);
+  f3 fy = normalize(cross(normal, fx));
+  bool flip_v = dot(fy, tv) < 0;
+  normalmap.y *= flip_v ? 1 : -1;
+  return normalize(fx * normalmap.x + fy * normalmap.y + normal * normalmap.z);
+}
+// eval_shading_normal, yocto_scene.cpp:476-503 (refractive keeps the geometric orientation)
+VPT_DEV f3 eval_shading_normal(const DScene& sc, const DInstance& inst, int element, f2 uv, f3 outgoing) {
+  const vpt_material& m = sc.materials[inst.material];
+  f3 normal = eval_normal(sc, inst, element, uv);
+  int ntex = m.normal_tex;
+  if (ntex != VPT_INVALID) normal = eval_normalmap(sc, inst, element, uv, normal, ntex);
+  if (m.type == VPT_MAT_REFRACTIVE) return normal;
+  return dot(normal, outgoing) >= 0 ? normal : -normal;
+}
+
+// ------------------------------------------------------------------------------------------------
+// material point, yocto_scene.h:292-304, yocto_scene.cpp:529-619
+// ------------------------------------------------------------------------------------------------
+struct mpoint {
+  int   type;
+  f3    emission, color;
+  float opacity, roughness, metallic, ior;
+  f3    density, scattering;
+  float scanisotropy;
+};
+#define VPT_MIN_ROUGHNESS (0.03f * 0.03f)
+
+VPT_DEV void finish_material(mpoint& p, float trdepth) {
+  if (p.type == VPT_MAT_REFRACTIVE || p.type == VPT_MAT_VOLUMETRIC || p.type == VPT_MAT_SUBSURFACE) {
+    f3 c      = vclamp(p.color, 0.0001f, 1.0f);
+    p.density = -mk3(logf(c.x), logf(c.y), logf(c.z)) / trdepth;
+  } else {
+    p.density = mk3(0, 0, 0);
+  }
+  if (p.type == VPT_MAT_MATTE || p.type == VPT_MAT_GLTFPBR || p.type == VPT_MAT_GLOSSY) p.roughness = clampf(p.roughness, VPT_MIN_ROUGHNESS, 1.0f);
+  else if (p.type == VPT_MAT_VOLUMETRIC) p.roughness = 0;
+  else if (p.roughness < VPT_MIN_ROUGHNESS) p.roughness = 0;
+}
+VPT_DEV mpoint eval_material(const DScene& sc, const DInstance& inst, int element, f2 uv) {
+  vpt_material m  = sc.materials[inst.material];
+  f2 texcoord     = eval_texcoord(sc, inst, element, uv);
+  f4 emission_tex = eval_texture(sc, m.emission_tex, texcoord, true);
+  f4 color_shp    = eval_color(sc, inst, element, uv);
+  f4 color_tex    = eval_texture(sc, m.color_tex, texcoord, true);
+  f4 rough_tex    = eval_texture(sc, m.roughness_tex, texcoord, false);
+  f4 scatter_tex  = eval_texture(sc, m.scattering_tex, texcoord, true);
+  mpoint p;
+  p.type         = m.type;
+  p.emission     = ld3(m.emission) * xyz(emission_tex);
+  p.color        = ld3(m.color) * xyz(color_tex) * xyz(color_shp);
+  p.opacity      = m.opacity * color_tex.w * color_shp.w;
+  p.metallic     = m.metallic * rough_tex.z;
+  p.roughness    = m.roughness * rough_tex.y;
+  p.roughness    = p.roughness * p.roughness;
+  p.ior          = m.ior;
+  p.scattering   = ld3(m.scattering) * xyz(scatter_tex);
+  p.scanisotropy = m.scanisotropy;
+  finish_material(p, m.trdepth);
+  return p;
+}
+VPT_DEV mpoint eval_material_plain(const DScene& sc, int mat) {   // yocto_scene.cpp:581-619
+  vpt_material m = sc.materials[mat];
+  mpoint p;
+  p.type = m.type, p.emission = ld3(m.emission), p.color = ld3(m.color), p.opacity = m.opacity;
+  p.metallic     = m.metallic;
+  p.roughness    = m.roughness;
+  p.roughness    = p.roughness * p.roughness;
+  p.ior = m.ior, p.scattering = ld3(m.scattering), p.scanisotropy = m.scanisotropy;
+  finish_material(p, m.trdepth);
+  return p;
+}
+VPT_DEV bool is_delta(const mpoint& m) {
+  return ((m.type == VPT_MAT_REFLECTIVE || m.type == VPT_MAT_REFRACTIVE || m.type == VPT_MAT_TRANSPARENT) && m.roughness == 0) ||
+         m.type == VPT_MAT_VOLUMETRIC;
+}
+VPT_DEV bool is_volumetric_type(int t) { return t == VPT_MAT_REFRACTIVE || t == VPT_MAT_VOLUMETRIC || t == VPT_MAT_SUBSURFACE; }
+
+// eval_environment, yocto_scene.cpp:634-651 (sum over all environments)
+VPT_DEV f3 eval_environment(const DScene& sc, f3 direction) {
+  f3 emission = mk3(0, 0, 0);
+  for (int e = 0; e < sc.num_environments; e++) {
+    vpt_environment env = sc.environments[e];
+    f3 wl = transform_direction(load_frame(sc.env_inv + 3 * e), direction);
+    f2 tc = mk2(atan2f(wl.z, wl.x) / (2 * VPT_PI), acosf(clampf(wl.y, -1.0f, 1.0f)) / VPT_PI);
+    if (tc.x < 0) tc.x += 1;
+    emission = emission + ld3(env.emission) * xyz(eval_texture(sc, env.emission_tex, tc, false));
+  }
+  return emission;
+}
+
+// eval_camera, yocto_scene.cpp:67-102
+VPT_DEV ray_t eval_camera(const vpt_camera& cam, f2 image_uv, f2 lens_uv) {
+  f2 film = cam.aspect >= 1 ? mk2(cam.film, cam.film / cam.aspect) : mk2(cam.film * cam.aspect, cam.film);
+  frame fr = load_frame(cam.frame);
+  if (!cam.orthographic) {
+    f3 q  = mk3(film.x * (0.5f - image_uv.x), film.y * (image_uv.y - 0.5f), cam.lens);
+    f3 dc = -normalize(q);
+    f3 e  = mk3(lens_uv.x * cam.aperture / 2, lens_uv.y * cam.aperture / 2, 0);
+    f3 p  = dc * cam.focus / fabs_(dc.z);
+    f3 d  = normalize(p - e);
+    return make_ray(transform_point(fr, e), transform_direction(fr, d));
+  } else {
+    float scale = 1 / cam.lens;
+    f3 q = mk3(film.x * (0.5f - image_uv.x) * scale, film.y * (image_uv.y - 0.5f) * scale, cam.lens);
+    f3 e = mk3(-q.x, -q.y, 0) + mk3(lens_uv.x * cam.aperture / 2, lens_uv.y * cam.aperture / 2, 0);
+    f3 p = mk3(-q.x, -q.y, -cam.focus);
+    f3 d = normalize(p - e);
+    return make_ray(transform_point(fr, e), transform_direction(fr, d));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampling warps, yocto_sampling.h:251-395
+// ------------------------------------------------------------------------------------------------
+VPT_DEV f3 sample_hemisphere_cos(f3 normal, f2 ruv) {
+  float z = sqrtf(ruv.y), r = sqrtf(1 - z * z), phi = 2 * VPT_PI * ruv.x;
+  return transform_direction(basis_fromz(normal), mk3(r * cosf(phi), r * sinf(phi), z));
+}
+VPT_DEV float sample_hemisphere_cos_pdf(f3 normal, f3 direction) {
+  float cosw = dot(normal, direction);
+  return (cosw <= 0) ? 0 : cosw / VPT_PI;
+}
+VPT_DEV f3 sample_sphere(f2 ruv) {
+  float z = 2 * ruv.y - 1, r = sqrtf(clampf(1 - z * z, 0.0f, 1.0f)), phi = 2 * VPT_PI * ruv.x;
+  return mk3(r * cosf(phi), r * sinf(phi), z);
+}
+VPT_DEV int sample_uniform(int size, float r) { return clampi((int)(r * size), 0, size - 1); }
+// sample_discrete: std::upper_bound over the CDF (yocto_sampling.h:385-390)
+VPT_DEV int sample_discrete(const float* cdf, int n, float r) {
+  float back = cdf[n - 1];
+  r = clampf(r * back, 0.0f, back - 0.00001f);
+  int lo = 0, len = n;
+  while (len > 0) {
+    int half = len >> 1;
+    if (!(r < cdf[lo + half])) lo += half + 1, len -= half + 1;
+    else len = half;
+  }
+  return clampi(lo, 0, n - 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BSDF lobes, yocto_shading.h:296-1039
+// ------------------------------------------------------------------------------------------------
+VPT_DEV bool same_hemisphere(f3 n, f3 o, f3 i) { return dot(n, o) * dot(n, i) >= 0; }
+VPT_DEV f3 fresnel_schlick(f3 specular, f3 normal, f3 outgoing) {
+  if (is_zero3(specular)) return mk3(0, 0, 0);
+  float cosine = dot(normal, outgoing);
+  return specular + (1 - specular) * powf(clampf(1 - fabs_(cosine), 0.0f, 1.0f), 5.0f);
+}
+VPT_DEV float fresnel_dielectric(float eta, f3 normal, f3 outgoing) {
+  float cosw = fabs_(dot(normal, outgoing));
+  float sin2 = 1 - cosw * cosw, eta2 = eta * eta;
+  float cos2t = 1 - sin2 / eta2;
+  if (cos2t < 0) return 1;
+  float t0 = sqrtf(cos2t), t1 = eta * t0, t2 = eta * cosw;
+  float rs = (cosw - t1) / (cosw + t1), rp = (t0 - t2) / (t0 + t2);
+  return (rs * rs + rp * rp) / 2;
+}
+VPT_DEV f3 fresnel_conductor(f3 eta, f3 etak, f3 normal, f3 outgoing) {
+  float cosw = dot(normal, outgoing);
+  if (cosw <= 0) return mk3(0, 0, 0);
+  cosw = clampf(cosw, -1.0f, 1.0f);
+  float cos2 = cosw * cosw, sin2 = clampf(1 - cos2, 0.0f, 1.0f);
+  f3 eta2 = eta * eta, etak2 = etak * etak;
+  f3 t0 = eta2 - etak2 - sin2;
+  f3 a2plusb2 = vsqrt(t0 * t0 + 4 * eta2 * etak2);
+  f3 t1 = a2plusb2 + cos2;
+  f3 a  = vsqrt((a2plusb2 + t0) / 2);
+  f3 t2 = 2 * a * cosw;
+  f3 rs = (t1 - t2) / (t1 + t2);
+  f3 t3 = cos2 * a2plusb2 + sin2 * sin2;
+  f3 t4 = t2 * sin2;
+  f3 rp = rs * (t3 - t4) / (t3 + t4);
+  return (rp + rs) / 2;
+}
+VPT_DEV f3 eta_to_reflectivity(f3 eta) { return ((eta - 1) * (eta - 1)) / ((eta + 1) * (eta + 1)); }
+VPT_DEV f3 reflectivity_to_eta(f3 r_) {
+  f3 r = vclamp(r_, 0.0f, 0.99f);
+  return (1 + vsqrt(r)) / (1 - vsqrt(r));
+}
+VPT_DEV float microfacet_distribution(float roughness, f3 normal, f3 halfway) {
+  float cosine = dot(normal, halfway);
+  if (cosine <= 0) return 0;
+  float r2 = roughness * roughness, c2 = cosine * cosine;
+  return r2 / (VPT_PI * (c2 * r2 + 1 - c2) * (c2 * r2 + 1 - c2));
+}
+VPT_DEV float microfacet_shadowing1(float roughness, f3 normal, f3 halfway, f3 direction) {
+  float cosine = dot(normal, direction), cosineh = dot(halfway, direction);
+  if (cosine * cosineh <= 0) return 0;
+  float r2 = roughness * roughness, c2 = cosine * cosine;
+  return 2 * fabs_(cosine) / (fabs_(cosine) + sqrtf(c2 - r2 * c2 + r2));
+}
+VPT_DEV float microfacet_shadowing(float roughness, f3 n, f3 h, f3 o, f3 i) {
+  return microfacet_shadowing1(roughness, n, h, o) * microfacet_shadowing1(roughness, n, h, i);
+}
+VPT_DEV f3 sample_microfacet(float roughness, f3 normal, f2 rn) {
+  float phi   = 2 * VPT_PI * rn.x;
+  float theta = atanf(roughness * sqrtf(rn.y / (1 - rn.y)));
+  f3 local = mk3(cosf(phi) * sinf(theta), sinf(phi) * sinf(theta), cosf(theta));
+  return transform_direction(basis_fromz(normal), local);
+}
+VPT_DEV float sample_microfacet_pdf(float roughness, f3 normal, f3 halfway) {
+  float cosine = dot(normal, halfway);
+  if (cosine < 0) return 0;
+  return microfacet_distribution(roughness, normal, halfway) * cosine;
+}
+VPT_DEV f3 upn(f3 n, f3 o) { return dot(n, o) <= 0 ? -n : n; }
+
+VPT_DEV f3 eval_matte(f3 color, f3 n, f3 o, f3 i) {
+  if (dot(n, i) * dot(n, o) <= 0) return mk3(0, 0, 0);
+  return color / VPT_PI * fabs_(dot(n, i));
+}
+VPT_DEV float sample_matte_pdf(f3 n, f3 o, f3 i) {
+  if (dot(n, i) * dot(n, o) <= 0) return 0;
+  return sample_hemisphere_cos_pdf(upn(n, o), i);
+}
+VPT_DEV f3 eval_glossy(f3 color, float ior, float roughness, f3 n, f3 o, f3 i) {
+  if (dot(n, i) * dot(n, o) <= 0) return mk3(0, 0, 0);
+  f3 up = upn(n, o);
+  float F1 = fresnel_dielectric(ior, up, o);
+  f3 h = normalize(i + o);
+  float F = fresnel_dielectric(ior, h, i);
+  float D = microfacet_distribution(roughness, up, h);
+  float G = microfacet_shadowing(roughness, up, h, o, i);
+  return color * (1 - F1) / VPT_PI * fabs_(dot(up, i)) + mk3(1, 1, 1) * F * D * G / (4 * dot(up, o) * dot(up, i)) * fabs_(dot(up, i));
+}
+VPT_DEV f3 sample_glossy(float ior, float roughness, f3 n, f3 o, float rnl, f2 rn) {
+  f3 up = upn(n, o);
+  if (rnl < fresnel_dielectric(ior, up, o)) {
+    f3 h = sample_microfacet(roughness, up, rn);
+    f3 i = reflect(o, h);
+    if (!same_hemisphere(up, o, i)) return mk3(0, 0, 0);
+    return i;
+  }
+  return sample_hemisphere_cos(up, rn);
+}
+VPT_DEV float sample_glossy_pdf(float ior, float roughness, f3 n, f3 o, f3 i) {
+  if (dot(n, i) * dot(n, o) <= 0) return 0;
+  f3 up = upn(n, o);
+  f3 h  = normalize(o + i);
+  float F = fresnel_dielectric(ior, up, o);
+  return F * sample_microfacet_pdf(roughness, up, h) / (4 * fabs_(dot(o, h))) + (1 - F) * sample_hemisphere_cos_pdf(up, i);
+}
+VPT_DEV f3 eval_reflective(f3 color, float roughness, f3 n, f3 o, f3 i) {
+  if (dot(n, i) * dot(n, o) <= 0) return mk3(0, 0, 0);
+  f3 up = upn(n, o);
+  f3 h  = normalize(i + o);
+  f3 F  = fresnel_conductor(reflectivity_to_eta(color), mk3(0, 0, 0), h, i);
+  float D = microfacet_distribution(roughness, up, h);
+  float G = microfacet_shadowing(roughness, up, h, o, i);
+  return F * D * G / (4 * dot(up, o) * dot(up, i)) * fabs_(dot(up, i));
+}
+VPT_DEV f3 sample_reflective(float roughness, f3 n, f3 o, f2 rn) {
+  f3 up = upn(n, o);
+  f3 h  = sample_microfacet(roughness, up, rn);
+  f3 i  = reflect(o, h);
+  if (!same_hemisphere(up, o, i)) return mk3(0, 0, 0);
+  return i;
+}
+VPT_DEV float sample_reflective_pdf(float roughness, f3 n, f3 o, f3 i) {
+  if (dot(n, i) * dot(n, o) <= 0) return 0;
+  f3 up = upn(n, o);
+  f3 h  = normalize(o + i);
+  return sample_microfacet_pdf(roughness, up, h) / (4 * fabs_(dot(o, h)));
+}
+VPT_DEV f3 gltf_reflectivity(f3 color, float ior, float metallic) { return lerp3(eta_to_reflectivity(mk3(ior, ior, ior)), color, metallic); }
+VPT_DEV f3 eval_gltfpbr(f3 color, float ior, float roughness, float metallic, f3 n, f3 o, f3 i) {
+  if (dot(n, i) * dot(n, o) <= 0) return mk3(0, 0, 0);
+  f3 refl = gltf_reflectivity(color, ior, metallic);
+  f3 up = upn(n, o);
+  f3 F1 = fresnel_schlick(refl, up, o);
+  f3 h  = normalize(i + o);
+  f3 F  = fresnel_schlick(refl, h, i);
+  float D = microfacet_distribution(roughness, up, h);
+  float G = microfacet_shadowing(roughness, up, h, o, i);
+  return color * (1 - metallic) * (1 - F1) / VPT_PI * fabs_(dot(up, i)) + F * D * G / (4 * dot(up, o) * dot(up, i)) * fabs_(dot(up, i));
+}
+VPT_DEV f3 sample_gltfpbr(f3 color, float ior, float roughness, float metallic, f3 n, f3 o, float rnl, f2 rn) {
+  f3 up = upn(n, o);
+  f3 refl = gltf_reflectivity(color, ior, metallic);
+  if (rnl < mean3(fresnel_schlick(refl, up, o))) {
+    f3 h = sample_microfacet(roughness, up, rn);
+    f3 i = reflect(o, h);
+    if (!same_hemisphere(up, o, i)) return mk3(0, 0, 0);
+    return i;
+  }
+  return sample_hemisphere_cos(up, rn);
+}
+VPT_DEV float sample_gltfpbr_pdf(f3 color, float ior, float roughness, float metallic, f3 n, f3 o, f3 i) {
+  if (dot(n, i) * dot(n, o) <= 0) return 0;
+  f3 up = upn(n, o);
+  f3 h  = normalize(o + i);
+  float F = mean3(fresnel_schlick(gltf_reflectivity(color, ior, metallic), up, o));
+  return F * sample_microfacet_pdf(roughness, up, h) / (4 * fabs_(dot(o, h))) + (1 - F) * sample_hemisphere_cos_pdf(up, i);
+}
+VPT_DEV f3 eval_transparent(f3 color, float ior, float roughness, f3 n, f3 o, f3 i) {
+  f3 up = upn(n, o);
+  if (dot(n, i) * dot(n, o) >= 0) {
+    f3 h = normalize(i + o);
+    float F = fresnel_dielectric(ior, h, o), D = microfacet_distribution(roughness, up, h);
+    float G = microfacet_shadowing(roughness, up, h, o, i);
+    return mk3(1, 1, 1) * F * D * G / (4 * dot(up, o) * dot(up, i)) * fabs_(dot(up, i));
+  } else {
+    f3 refl = reflect(-i, up);
+    f3 h = normalize(refl + o);
+    float F = fresnel_dielectric(ior, h, o), D = microfacet_distribution(roughness, up, h);
+    float G = microfacet_shadowing(roughness, up, h, o, refl);
+    return color * (1 - F) * D * G / (4 * dot(up, o) * dot(up, refl)) * (fabs_(dot(up, refl)));
+  }
+}
+VPT_DEV f3 sample_transparent(float ior, float roughness, f3 n, f3 o, float rnl, f2 rn) {
+  f3 up = upn(n, o);
+  f3 h  = sample_microfacet(roughness, up, rn);
+  if (rnl < fresnel_dielectric(ior, h, o)) {
+    f3 i = reflect(o, h);
+    if (!same_hemisphere(up, o, i)) return mk3(0, 0, 0);
+    return i;
+  } else {
+    f3 refl = reflect(o, h);
+    f3 i = -reflect(refl, up);
+    if (same_hemisphere(up, o, i)) return mk3(0, 0, 0);
+    return i;
+  }
+}
+VPT_DEV float sample_transparent_pdf(float ior, float roughness, f3 n, f3 o, f3 i) {
+  f3 up = upn(n, o);
+  if (dot(n, i) * dot(n, o) >= 0) {
+    f3 h = normalize(i + o);
+    return fresnel_dielectric(ior, h, o) * sample_microfacet_pdf(roughness, up, h) / (4 * fabs_(dot(o, h)));
+  } else {
+    f3 refl = reflect(-i, up);
+    f3 h = normalize(refl + o);
+    float d = (1 - fresnel_dielectric(ior, h, o)) * sample_microfacet_pdf(roughness, up, h);
+    return d / (4 * fabs_(dot(o, h)));
+  }
+}
+VPT_DEV f3 eval_refractive(float ior, float roughness, f3 n, f3 o, f3 i) {
+  bool entering = dot(n, o) >= 0;
+  f3 up = entering ? n : -n;
+  float rel_ior = entering ? ior : (1 / ior);
+  if (dot(n, i) * dot(n, o) >= 0) {
+    f3 h = normalize(i + o);
+    float F = fresnel_dielectric(rel_ior, h, o), D = microfacet_distribution(roughness, up, h);
+    float G = microfacet_shadowing(roughness, up, h, o, i);
+    return mk3(1, 1, 1) * F * D * G / fabs_(4 * dot(n, o) * dot(n, i)) * fabs_(dot(n, i));
+  } else {
+    f3 h = -normalize(rel_ior * i + o) * (entering ? 1.0f : -1.0f);
+    float F = fresnel_dielectric(rel_ior, h, o), D = microfacet_distribution(roughness, up, h);
+    float G = microfacet_shadowing(roughness, up, h, o, i);
+    return mk3(1, 1, 1) * fabs_((dot(o, h) * dot(i, h)) / (dot(o, n) * dot(i, n))) * (1 - F) * D * G /
+           powf(rel_ior * dot(h, i) + dot(h, o), 2.0f) * fabs_(dot(n, i));
+  }
+}
+VPT_DEV f3 sample_refractive(float ior, float roughness, f3 n, f3 o, float rnl, f2 rn) {
+  bool entering = dot(n, o) >= 0;
+  f3 up = entering ? n : -n;
+  f3 h  = sample_microfacet(roughness, up, rn);
+  if (rnl < fresnel_dielectric(entering ? ior : (1 / ior), h, o)) {
+    f3 i = reflect(o, h);
+    if (!same_hemisphere(up, o, i)) return mk3(0, 0, 0);
+    return i;
+  } else {
+    f3 i = refract(o, h, entering ? (1 / ior) : ior);
+    if (same_hemisphere(up, o, i)) return mk3(0, 0, 0);
+    return i;
+  }
+}
+VPT_DEV float sample_refractive_pdf(float ior, float roughness, f3 n, f3 o, f3 i) {
+  bool entering = dot(n, o) >= 0;
+  f3 up = entering ? n : -n;
+  float rel_ior = entering ? ior : (1 / ior);
+  if (dot(n, i) * dot(n, o) >= 0) {
+    f3 h = normalize(i + o);
+    return fresnel_dielectric(rel_ior, h, o) * sample_microfacet_pdf(roughness, up, h) / (4 * fabs_(dot(o, h)));
+  } else {
+    f3 h = -normalize(rel_ior * i + o) * (entering ? 1.0f : -1.0f);
+    return (1 - fresnel_dielectric(rel_ior, h, o)) * sample_microfacet_pdf(roughness, up, h) * fabs_(dot(h, i)) /
+           powf(rel_ior * dot(h, i) + dot(h, o), 2.0f);
+  }
+}
+// delta lobes
+VPT_DEV f3 eval_refractive_delta(float ior, f3 n, f3 o, f3 i) {
+  if (fabs_(ior - 1) < 1e-3f) return dot(n, i) * dot(n, o) <= 0 ? mk3(1, 1, 1) : mk3(0, 0, 0);
+  bool entering = dot(n, o) >= 0;
+  f3 up = entering ? n : -n;
+  float rel_ior = entering ? ior : (1 / ior);
+  if (dot(n, i) * dot(n, o) >= 0) return mk3(1, 1, 1) * fresnel_dielectric(rel_ior, up, o);
+  return mk3(1, 1, 1) * (1 / (rel_ior * rel_ior)) * (1 - fresnel_dielectric(rel_ior, up, o));
+}
+VPT_DEV f3 sample_refractive_delta(float ior, f3 n, f3 o, float rnl) {
+  if (fabs_(ior - 1) < 1e-3f) return -o;
+  bool entering = dot(n, o) >= 0;
+  f3 up = entering ? n : -n;
+  float rel_ior = entering ? ior : (1 / ior);
+  if (rnl < fresnel_dielectric(rel_ior, up, o)) return reflect(o, up);
+  return refract(o, up, 1 / rel_ior);
+}
+VPT_DEV float sample_refractive_delta_pdf(float ior, f3 n, f3 o, f3 i) {
+  if (fabs_(ior - 1) < 1e-3f) return dot(n, i) * dot(n, o) < 0 ? 1.0f : 0.0f;
+  bool entering = dot(n, o) >= 0;
+  f3 up = entering ? n : -n;
+  float rel_ior = entering ? ior : (1 / ior);
+  if (dot(n, i) * dot(n, o) >= 0) return fresnel_dielectric(rel_ior, up, o);
+  return (1 - fresnel_dielectric(rel_ior, up, o));
+}
+
+// material dispatch, yocto_pathtrace.cpp:86-236
+VPT_DEV f3 eval_emission(f3 emission, f3 normal, f3 outgoing) { return dot(normal, outgoing) >= 0 ? emission : mk3(0, 0, 0); }
+VPT_DEV f3 eval_bsdfcos(const mpoint& m, f3 n, f3 o, f3 i) {
+  if (m.roughness == 0) return mk3(0, 0, 0);
+  switch (m.type) {
+    case VPT_MAT_MATTE: return eval_matte(m.color, n, o, i);
+    case VPT_MAT_GLOSSY: return eval_glossy(m.color, m.ior, m.roughness, n, o, i);
+    case VPT_MAT_REFLECTIVE: return eval_reflective(m.color, m.roughness, n, o, i);
+    case VPT_MAT_TRANSPARENT: return eval_transparent(m.color, m.ior, m.roughness, n, o, i);
+    case VPT_MAT_REFRACTIVE:
+    case VPT_MAT_SUBSURFACE: return eval_refractive(m.ior, m.roughness, n, o, i);
+    case VPT_MAT_GLTFPBR: return eval_gltfpbr(m.color, m.ior, m.roughness, m.metallic, n, o, i);
+    default: return mk3(0, 0, 0);
+  }
+}
+VPT_DEV f3 sample_bsdfcos(const mpoint& m, f3 n, f3 o, float rnl, f2 rn) {
+  if (m.roughness == 0) return mk3(0, 0, 0);
+  switch (m.type) {
+    case VPT_MAT_MATTE: return sample_hemisphere_cos(upn(n, o), rn);
+    case VPT_MAT_GLOSSY: return sample_glossy(m.ior, m.roughness, n, o, rnl, rn);
+    case VPT_MAT_REFLECTIVE: return sample_reflective(m.roughness, n, o, rn);
+    case VPT_MAT_TRANSPARENT: return sample_transparent(m.ior, m.roughness, n, o, rnl, rn);
+    case VPT_MAT_REFRACTIVE:
+    case VPT_MAT_SUBSURFACE: return sample_refractive(m.ior, m.roughness, n, o, rnl, rn);
+    case VPT_MAT_GLTFPBR: return sample_gltfpbr(m.color, m.ior, m.roughness, m.metallic, n, o, rnl, rn);
+    default: return mk3(0, 0, 0);
+  }
+}
+VPT_DEV float sample_bsdfcos_pdf(const mpoint& m, f3 n, f3 o, f3 i) {
+  if (m.roughness == 0) return 0;
+  switch (m.type) {
+    case VPT_MAT_MATTE: return sample_matte_pdf(n, o, i);
+    case VPT_MAT_GLOSSY: return sample_glossy_pdf(m.ior, m.roughness, n, o, i);
+    case VPT_MAT_REFLECTIVE: return sample_reflective_pdf(m.roughness, n, o, i);
+    case VPT_MAT_TRANSPARENT: return sample_transparent_pdf(m.ior, m.roughness, n, o, i);
+    case VPT_MAT_REFRACTIVE:
+    case VPT_MAT_SUBSURFACE: return sample_refractive_pdf(m.ior, m.roughness, n, o, i);
+    case VPT_MAT_GLTFPBR: return sample_gltfpbr_pdf(m.color, m.ior, m.roughness, m.metallic, n, o, i);
+    default: return 0;
+  }
+}
+VPT_DEV f3 eval_delta(const mpoint& m, f3 n, f3 o, f3 i) {
+  if (m.roughness != 0) return mk3(0, 0, 0);
+  switch (m.type) {
+    case VPT_MAT_REFLECTIVE:
+      if (dot(n, i) * dot(n, o) <= 0) return mk3(0, 0, 0);
+      return fresnel_conductor(reflectivity_to_eta(m.color), mk3(0, 0, 0), upn(n, o), o);
+    case VPT_MAT_TRANSPARENT: {
+      f3 up = upn(n, o);
+      if (dot(n, i) * dot(n, o) >= 0) return mk3(1, 1, 1) * fresnel_dielectric(m.ior, up, o);
+      return m.color * (1 - fresnel_dielectric(m.ior, up, o));
+    }
+    case VPT_MAT_REFRACTIVE: return eval_refractive_delta(m.ior, n, o, i);
+    case VPT_MAT_VOLUMETRIC: return dot(n, i) * dot(n, o) >= 0 ? mk3(0, 0, 0) : mk3(1, 1, 1);
+    default: return mk3(0, 0, 0);
+  }
+}
+VPT_DEV f3 sample_delta(const mpoint& m, f3 n, f3 o, float rnl) {
+  if (m.roughness != 0) return mk3(0, 0, 0);
+  switch (m.type) {
+    case VPT_MAT_REFLECTIVE: return reflect(o, upn(n, o));
+    case VPT_MAT_TRANSPARENT: {
+      f3 up = upn(n, o);
+      if (rnl < fresnel_dielectric(m.ior, up, o)) return reflect(o, up);
+      return -o;
+    }
+    case VPT_MAT_REFRACTIVE: return sample_refractive_delta(m.ior, n, o, rnl);
+    case VPT_MAT_VOLUMETRIC: return -o;
+    default: return mk3(0, 0, 0);
+  }
+}
+VPT_DEV float sample_delta_pdf(const mpoint& m, f3 n, f3 o, f3 i) {
+  if (m.roughness != 0) return 0;
+  switch (m.type) {
+    case VPT_MAT_REFLECTIVE: return dot(n, i) * dot(n, o) <= 0 ? 0.0f : 1.0f;
+    case VPT_MAT_TRANSPARENT: {
+      f3 up = upn(n, o);
+      if (dot(n, i) * dot(n, o) >= 0) return fresnel_dielectric(m.ior, up, o);
+      return 1 - fresnel_dielectric(m.ior, up, o);
+    }
+    case VPT_MAT_REFRACTIVE: return sample_refractive_delta_pdf(m.ior, n, o, i);
+    case VPT_MAT_VOLUMETRIC: return dot(n, i) * dot(n, o) >= 0 ? 0.0f : 1.0f;
+    default: return 0;
+  }
+}
+
+// media, yocto_shading.h:1047-1102
+VPT_DEV f3 vexp3(f3 a) { return mk3(expf(a.x), expf(a.y), expf(a.z)); }
+VPT_DEV float sample_transmittance(f3 density, float max_distance, float rl, float rd) {
+  int   channel  = clampi((int)(rl * 3), 0, 2);
+  float dc       = comp(density, channel);
+  float distance = (dc == 0) ? VPT_FLT_MAX : -logf(1 - rd) / dc;
+  return fmin_(distance, max_distance);
+}
+VPT_DEV float sample_transmittance_pdf(f3 density, float distance, float max_distance) {
+  if (distance < max_distance) return sum3(density * vexp3(-density * distance)) / 3;
+  return sum3(vexp3(-density * max_distance)) / 3;
+}
+VPT_DEV float eval_phasefunction(float g, f3 outgoing, f3 incoming) {
+  float cosine = -dot(outgoing, incoming);
+  float denom  = 1 + g * g - 2 * g * cosine;
+  return (1 - g * g) / (4 * VPT_PI * denom * sqrtf(denom));
+}
+VPT_DEV f3 sample_phasefunction(float g, f3 outgoing, f2 rn) {
+  float cos_theta = 0.0f;
+  if (fabs_(g) < 1e-3f) {
+    cos_theta = 1 - 2 * rn.y;
+  } else {
+    float square = (1 - g * g) / (1 + g - 2 * g * rn.y);
+    cos_theta    = (1 + g * g - square * square) / (2 * g);
+  }
+  float sin_theta = sqrtf(fmax_(0.0f, 1 - cos_theta * cos_theta));
+  float phi = 2 * VPT_PI * rn.x;
+  return mul(basis_fromz(-outgoing), mk3(sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta));
+}
+
+// ------------------------------------------------------------------------------------------------
+// SDF module, yocto_sdfs.h:43-80, yocto_sdfs.cpp:7-127, yocto_pathtrace.cpp:259-307
+// ------------------------------------------------------------------------------------------------
+VPT_DEV float sd_box(f3 p, f3 b) {
+  f3 d = vabs(p) - b;
+  return fmin_(fmax_(d.x, fmax_(d.y, d.z)), 0.0f) + length(vmaxs(d, 0.0f));
+}
+VPT_DEV float sd_bbox(f3 p, f3 b, float e) {
+  p    = vabs(p) - b;
+  f3 q = vabs(p + e) - e;
+  return fmin_(fmin_(length(vmaxs(mk3(p.x, q.y, q.z), 0.0f)) + fmin_(fmax_(p.x, fmax_(q.y, q.z)), 0.0f),
+                   length(vmaxs(mk3(q.x, p.y, q.z), 0.0f)) + fmin_(fmax_(q.x, fmax_(p.y, q.z)), 0.0f)),
+      length(vmaxs(mk3(q.x, q.y, p.z), 0.0f)) + fmin_(fmax_(q.x, fmax_(q.y, p.z)), 0.0f));
+}
+VPT_DEV float sd_capped_cone(f3 p, float h, float r1, float r2) {
+  f2 q  = mk2(length(mk2(p.x, p.z)), p.y);
+  f2 k1 = mk2(r2, h), k2 = mk2(r2 - r1, 2.0f * h);
+  f2 ca = mk2(q.x - fmin_(q.x, (q.y < 0.0f) ? r1 : r2), fabs_(q.y) - h);
+  f2 cb = q - k1 + k2 * clampf(dot(k1 - q, k2) / dot(k2, k2), 0.0f, 1.0f);
+  float s = (cb.x < 0.0f && ca.y < 0.0f) ? -1.0f : 1.0f;
+  return s * sqrtf(fmin_(dot(ca, ca), dot(cb, cb)));
+}
+VPT_DEV float eval_sdf_function(const vpt_sdf& sdf, f3 p) {
+  switch (sdf.type) {
+    case VPT_SDF_BBOX: return sd_bbox(p, mk3(sdf.p[1], sdf.p[2], sdf.p[3]), sdf.p[0]);
+    case VPT_SDF_BOX: return sd_box(p - (ld3(sdf.whd) * 0.5f), ld3(sdf.whd) * 0.5f);
+    case VPT_SDF_CAPPED_CONE: return sd_capped_cone(p, sdf.p[0], sdf.p[1], sdf.p[2]);
+    case VPT_SDF_PLANE: return p.y;
+    case VPT_SDF_SPHERE: return length(p) - sdf.p[0];
+    case VPT_SDF_TORUS: return length(mk2(length(mk2(p.x, p.z)) - sdf.p[0], p.y)) - sdf.p[1];
+    default: return VPT_FLT_MAX;
+  }
+}
+// eval_volume: 8-tap trilinear in the reference's term order, yocto_sdfs.cpp:92-127
+VPT_DEV float eval_volume(const DScene& sc, const vpt_volume& vol, f3 uvw) {
+  int W = vol.whd[0], H = vol.whd[1], D = vol.whd[2];
+  if ((long long)W * H * D == 0) return 0;
+  float s = clampf((uvw.x + 1.0f) * 0.5f, 0.0f, 1.0f) * (W - 1);
+  float t = clampf((uvw.y + 1.0f) * 0.5f, 0.0f, 1.0f) * (H - 1);
+  float r = clampf((uvw.z + 1.0f) * 0.5f, 0.0f, 1.0f) * (D - 1);
+  int i = clampi((int)s, 0, W - 1), j = clampi((int)t, 0, H - 1), k = clampi((int)r, 0, D - 1);
+  int ii = min(i + 1, W - 1), jj = min(j + 1, H - 1), kk = min(k + 1, D - 1);
+  float u = s - i, v = t - j, w = r - k;
+  const float* vox = sc.voxels + vol.offset;
+  long long WH = (long long)W * H;
+  float v000 = vox[i + (long long)j * W + k * WH], v100 = vox[ii + (long long)j * W + k * WH];
+  float v010 = vox[i + (long long)jj * W + k * WH], v001 = vox[i + (long long)j * W + kk * WH];
+  float v011 = vox[i + (long long)jj * W + kk * WH], v101 = vox[ii + (long long)j * W + kk * WH];
+  float v110 = vox[ii + (long long)jj * W + k * WH], v111 = vox[ii + (long long)jj * W + kk * WH];
+  return v000 * (1 - u) * (1 - v) * (1 - w) + v100 * u * (1 - v) * (1 - w) + v010 * (1 - u) * v * (1 - w) +
+         v001 * (1 - u) * (1 - v) * w + v011 * (1 - u) * v * w + v101 * u * (1 - v) * w + v110 * u * v * (1 - w) +
+         v111 * u * v * w;
+}
+VPT_DEV float eval_sdf_grid(const DScene& sc, const vpt_volume_instance& inst, f3 p, float t) {   // yocto_sdfs.cpp:30-49
+  vpt_volume vol = sc.volumes[inst.volume];
+  f3 grid_res = mk3((float)vol.whd[0], (float)vol.whd[1], (float)vol.whd[2]);
+  f3 origin   = ld3(inst.frame.o);
+  f3 bbox_max  = origin + (vol.res * grid_res) * inst.scalef;
+  f3 bbox_size = (bbox_max - origin);
+  float bbox_dist = sd_box(p - (bbox_size * 0.5f), (bbox_size * 0.5f));
+  if (bbox_dist < VPT_FLT_EPS * t) {
+    f3 uvw = p * 2.f / (bbox_size)-1;
+    return eval_volume(sc, vol, uvw) * inst.scalef;
+  }
+  return bbox_dist;
+}
+struct sdf_hit { float result; int instance, sdf; };
+VPT_DEV sdf_hit eval_sdf_scene(const DScene& sc, f3 p, float t) {   // yocto_sdfs.cpp:7-26 (first minimum wins ties)
+  sdf_hit res = {VPT_FLT_MAX, -1, -1};
+  for (int idx = 0; idx < sc.num_vol_instances; idx++) {
+    vpt_volume_instance inst = sc.vol_instances[idx];
+    float d = eval_sdf_grid(sc, inst, transform_point(load_frame(inst.frame), p), t);
+    if (d < res.result) res.result = d, res.instance = idx, res.sdf = -1;
+  }
+  for (int idx = 0; idx < sc.num_sdfs; idx++) {
+    vpt_sdf sdf = sc.sdfs[idx];
+    float d = eval_sdf_function(sdf, transform_point(load_frame(sdf.frame), p));
+    if (d < res.result) res.result = d, res.instance = -1, res.sdf = idx;
+  }
+  return res;
+}
+// tetrahedral 4-tap normals, yocto_sdfs.cpp:67-89
+VPT_DEV f3 eval_sdf_normal_function(const vpt_sdf& sdf, f3 p, float t) {
+  float h = VPT_FLT_EPS * t;
+  frame f = load_frame(sdf.frame);
+  float d1 = eval_sdf_function(sdf, transform_point(f, p + mk3(1, -1, -1) * h));
+  float d2 = eval_sdf_function(sdf, transform_point(f, p + mk3(-1, -1, 1) * h));
+  float d3 = eval_sdf_function(sdf, transform_point(f, p + mk3(-1, 1, -1) * h));
+  float d4 = eval_sdf_function(sdf, transform_point(f, p + mk3(1, 1, 1) * h));
+  return normalize(mk3(1, -1, -1) * d1 + mk3(-1, -1, 1) * d2 + mk3(-1, 1, -1) * d3 + mk3(1, 1, 1) * d4);
+}
+VPT_DEV f3 eval_sdf_normal_grid(const DScene& sc, const vpt_volume_instance& inst, f3 p, float t) {
+  float h = VPT_FLT_EPS * t;
+  frame f = load_frame(inst.frame);
+  float d1 = eval_sdf_grid(sc, inst, transform_point(f, p + mk3(1, -1, -1) * h), t);
+  float d2 = eval_sdf_grid(sc, inst, transform_point(f, p + mk3(-1, -1, 1) * h), t);
+  float d3 = eval_sdf_grid(sc, inst, transform_point(f, p + mk3(-1, 1, -1) * h), t);
+  float d4 = eval_sdf_grid(sc, inst, transform_point(f, p + mk3(1, 1, 1) * h), t);
+  return normalize(mk3(1, -1, -1) * d1 + mk3(-1, -1, 1) * d2 + mk3(-1, 1, -1) * d3 + mk3(1, 1, 1) * d4);
+}
+struct st_hit { bool hit; float dist; int instance, sdf; };
+VPT_DEV st_hit spheretrace_one(const DScene& sc, f3 ro, f3 rd, int sdf_handle, int maxiter) {   // cpp:267-286
+  st_hit r = {false, VPT_FLT_MAX, -1, -1};
+  float  t = VPT_RAY_EPS;
+  vpt_sdf sdf = sc.sdfs[sdf_handle];
+  frame  f   = load_frame(sdf.frame);
+  for (int i = 0; i < maxiter && t < VPT_FLT_MAX; ++i) {
+    float res = eval_sdf_function(sdf, transform_point(f, ro + rd * t));
+    if (fabs_(res) < (VPT_FLT_EPS * t)) {
+      r.hit = true, r.dist = t, r.sdf = sdf_handle;
+      return r;
+    }
+    t += res;
+  }
+  return r;
+}
+VPT_DEV st_hit spheretrace(const DScene& sc, const ray_t& ray, int maxiter) {   // cpp:289-307
+  st_hit r = {false, VPT_FLT_MAX, -1, -1};
+  float  t = ray.tmin;
+  for (int i = 0; i < maxiter && t < ray.tmax; ++i) {
+    sdf_hit res = eval_sdf_scene(sc, ray_point(ray, t), t);
+    if (fabs_(res.result) < (VPT_FLT_EPS * t)) {
+      r.hit = true, r.dist = t, r.instance = res.instance, r.sdf = res.sdf;
+      return r;
+    }
+    t += res.result;
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lights, yocto_pathtrace.cpp:312-421
+// ------------------------------------------------------------------------------------------------
+VPT_DEV f3 sample_lights(const DScene& sc, f3 position, float rl, float rel, f2 ruv) {
+  int       light_id = sample_uniform(sc.num_lights, rl);
+  vpt_light light    = sc.lights[light_id];
+  const float* cdf   = sc.light_cdf + light.cdf_offset;
+  if (light.instance != VPT_INVALID) {
+    const DInstance& inst = sc.instances[light.instance];
+    int element = sample_discrete(cdf, light.cdf_len, rel);
+    f2  uv      = sc.shapes[inst.shape].is_triangles ? mk2(1 - sqrtf(ruv.x), ruv.y * sqrtf(ruv.x)) : ruv;
+    return normalize(eval_position(sc, inst, element, uv) - position);
+  } else if (light.sdf != VPT_INVALID) {
+    vpt_sdf sdf = sc.sdfs[light.sdf];
+    f3 wlightp  = transform_point(load_frame(sc.sdf_inv + 3 * light.sdf), mk3(ruv.x, ruv.y, 1) * ld3(sdf.whd));
+    return normalize(wlightp - position);
+  } else if (light.environment != VPT_INVALID) {
+    vpt_environment env = sc.environments[light.environment];
+    if (env.emission_tex != VPT_INVALID) {
+      int tw = sc.textures[env.emission_tex].width, th = sc.textures[env.emission_tex].height;
+      int idx = sample_discrete(cdf, light.cdf_len, rel);
+      f2  uv  = mk2(((idx % tw) + 0.5f) / tw, ((idx / tw) + 0.5f) / th);
+      return transform_direction(load_frame(env.frame),
+          mk3(cosf(uv.x * 2 * VPT_PI) * sinf(uv.y * VPT_PI), cosf(uv.y * VPT_PI), sinf(uv.x * 2 * VPT_PI) * sinf(uv.y * VPT_PI)));
+    }
+    return sample_sphere(ruv);
+  }
+  return mk3(0, 0, 0);
+}
+VPT_DEV float sample_lights_pdf(const DScene& sc, f3 position, f3 direction, int maxiter, const lane_stack& stk) {
+  float pdf = 0.0f;
+  for (int l = 0; l < sc.num_lights; l++) {
+    vpt_light    light = sc.lights[l];
+    const float* cdf   = sc.light_cdf + light.cdf_offset;
+    if (light.instance != VPT_INVALID) {
+      const DInstance& inst = sc.instances[light.instance];
+      float area = cdf[light.cdf_len - 1];
+      float lpdf = 0.0f;
+      f3    next_position = position;
+      for (int bounce = 0; bounce < 100; bounce++) {
+        hit_t h = trace_instance(sc, light.instance, next_position, direction, stk);
+        if (!h.hit) break;
+        f3 lposition = eval_position(sc, inst, h.element, h.uv);
+        f3 lnormal   = eval_element_normal(sc, inst, h.element);
+        lpdf += distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * area);
+        next_position = lposition + direction * 1e-3f;
+      }
+      pdf += lpdf;
+    } else if (light.sdf != VPT_INVALID) {
+      st_hit h = spheretrace_one(sc, position, direction, light.sdf, maxiter);
+      if (h.hit) {
+        f3 lposition = position + direction * h.dist;
+        f3 lnormal   = eval_sdf_normal_function(sc.sdfs[h.sdf], position, h.dist);   // (sic) at `position`, cpp:389
+        float area   = cdf[light.cdf_len - 1];
+        pdf += distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * area);
+      }
+    } else if (light.environment != VPT_INVALID) {
+      vpt_environment env = sc.environments[light.environment];
+      if (env.emission_tex != VPT_INVALID) {
+        int tw = sc.textures[env.emission_tex].width, th = sc.textures[env.emission_tex].height;
+        f3 wl = transform_direction(load_frame(sc.env_inv + 3 * light.environment), direction);
+        f2 tc = mk2(atan2f(wl.z, wl.x) / (2 * VPT_PI), acosf(clampf(wl.y, -1.0f, 1.0f)) / VPT_PI);
+        if (tc.x < 0) tc.x += 1;
+        int i = clampi((int)(tc.x * tw), 0, tw - 1), j = clampi((int)(tc.y * th), 0, th - 1);
+        int idx = j * tw + i;
+        float prob  = (idx == 0 ? cdf[0] : cdf[idx] - cdf[idx - 1]) / cdf[light.cdf_len - 1];
+        float angle = (2 * VPT_PI / tw) * (VPT_PI / th) * sinf(VPT_PI * (j + 0.5f) / th);
+        pdf += prob / angle;
+      } else {
+        pdf += 1 / (4 * VPT_PI);
+      }
+    }
+  }
+  pdf *= (float)1 / (float)sc.num_lights;
+  return pdf;
+}

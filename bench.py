@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the HIP integrator on BASELINE.json's config[1]:
+tests/03_volume, --shader volpathtrace --bounces 64, 1280 wide (x533: camera aspect 2.4), 256 spp.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A *step* is one launch of the hot path over the whole frame: `--spp` (256) samples for every
+pixel, with the pixel state (radiance sums, hit counts, PCG32 streams) already resident in HBM in
+the tile-major layout of include/vpt.h.  With N GPUs the frame is cut into 8x8-pixel tiles dealt
+round-robin to the ranks (tile t -> rank t % N); each step ends with an RCCL all_gather of the
+ranks' tile buffers over xGMI and a resolve kernel on every rank.  Scaling is
+reported as WEAK: the per-GPU pixel count is fixed, i.e. the frame is 1280*sqrt(N) wide (N=8 ->
+3620x1508, the size class of BASELINE config[4]); `--strong` keeps the 1280-wide frame instead.
+
+The JSON line carries, besides the driver's contract:
+  roofline      algorithmic bytes per launch (SURVEY §8(d) formula, event counts measured by the CPU
+                oracle on a bounded sample of the same workload) / mean kernel time from HIP events
+                on the launch stream, against the 8 TB/s HBM peak.
+  cpu_baseline  the reference's own renderer (oracle/_ref/ref_driver, "reference") or, where that
+                binary is absent, our CPU restatement ("port"), timed on this host's cores on a
+                bounded sample (default 640x267x8 spp) of the same workload.  Rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SCENE = os.path.join(ROOT, "tests", "golden", "scenes", "03_volume", "volume.json")
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_sample(c):
+    """B = 32*(scene+shape nodes) + 64*instance tests + 4*(instance+prim tests)
+    + P*prim tests + 16*f32 texels + 4*u8 texels + 4*cdf probes + V*surface hits + 72."""
+    n = float(c["samples"])
+    prim = c["quad_tests"] + c["tri_tests"]
+    b = (32.0 * (c["scene_nodes"] + c["shape_nodes"]) + 64.0 * c["instance_tests"]
+         + 4.0 * (c["instance_tests"] + prim) + 64.0 * c["quad_tests"] + 48.0 * c["tri_tests"]
+         + 16.0 * c["texel_f32"] + 4.0 * c["texel_u8"] + 4.0 * c["cdf_probes"] + 80.0 * c["surface_hits"]
+         + 4.0 * c["voxel_fetches"] + 64.0 * c["sdf_evals"]) / n + 72.0
+    return b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step")
+    ap.add_argument("--resolution", type=int, default=1280)
+    ap.add_argument("--bounces", type=int, default=64)
+    ap.add_argument("--shader", default="volpathtrace")
+    ap.add_argument("--scene", default=SCENE)
+    ap.add_argument("--strong", action="store_true", help="fixed 1280-wide frame for every N")
+    ap.add_argument("--cpu-sample", default="640x8", help="cpu baseline sample: <resolution>x<spp>; '0' disables")
+    ap.add_argument("--tile", type=int, default=8)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import vpt_loader
+    vpt = vpt_loader.load()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    resolution = args.resolution if args.strong else int(round(args.resolution * (world ** 0.5)))
+    scene = vpt.HostScene(args.scene)
+    # params.samples bounds the progressive render; keep it out of reach (and != 1: preview branch)
+    params = vpt.PathtraceParams(resolution=resolution, samples=1 << 30, shader=args.shader, bounces=args.bounces)
+    state = scene.make_state(params)
+    width, height = state.width, state.height
+    dev = vpt.DeviceScene(scene, local_rank)
+    layout = vpt.VptLayout(width, height, args.tile, args.tile, rank, world)
+    slots = vpt.layout_slots(layout)
+    device = torch.device("cuda", local_rank)
+    d_image = torch.zeros((slots, 4), dtype=torch.float32, device=device)
+    d_hits = torch.zeros((slots,), dtype=torch.int32, device=device)
+    d_rng = torch.zeros((slots, 2), dtype=torch.int64, device=device)
+    vpt.state_upload(layout, state, d_image.data_ptr(), d_hits.data_ptr(), d_rng.data_ptr())
+    gathered = torch.empty((world * slots, 4), dtype=torch.float32, device=device) if world > 1 else d_image
+    frame = torch.empty((height, width, 4), dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    done = [0]
+    kernel_ms = []
+
+    def step(record):
+        dev.render_device(params, layout, args.spp, d_image.data_ptr(), d_hits.data_ptr(), d_rng.data_ptr(), stream)
+        done[0] += args.spp
+        if record:
+            kernel_ms.append(dev.last_kernel_ms())
+        if world > 1:  # tile buffers of all ranks over xGMI, then de-interleave on every rank
+            dist.all_gather_into_tensor(gathered, d_image)
+        vpt.resolve_device(layout, gathered.data_ptr(), done[0], frame.data_ptr(), stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples_per_step = width * height * args.spp
+    value = samples_per_step * args.steps / elapsed * 1e-6
+
+    roofline, cpu_baseline = None, None
+    if rank == 0:
+        import oracle_lib  # the checker, used here only for the reported CPU baseline and event counts
+        # --- event counts on a bounded sample of the same workload (oracle, all host threads) ------
+        cres, cspp = 320, 4
+        cparams = vpt.PathtraceParams(resolution=cres, samples=1 << 30, shader=args.shader, bounces=args.bounces)
+        cstate = scene.make_state(cparams)
+        counters = oracle_lib.oracle_render(scene, cparams, cstate, cspp, nthreads=0, counters=True)
+        bps = algorithmic_bytes_per_sample(counters)
+        # this rank's share of a launch
+        per_launch_samples = samples_per_step / world
+        mean_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        achieved = bps * per_launch_samples / (mean_ms * 1e-3) * 1e-9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "kernel": "vpt_render_kernel<%s>" % args.shader, "kernel_ms": round(mean_ms, 3),
+                    "algorithmic_bytes_per_sample": round(bps, 1)}
+        if world == 1 and args.cpu_sample != "0":
+            sres, sspp = (int(x) for x in args.cpu_sample.split("x"))
+            ncores = os.cpu_count() or 1
+            if oracle_lib.have_reference():
+                *_, info = oracle_lib.reference_render(args.scene, args.shader, sres, sspp, args.bounces,
+                                                       workdir=os.environ.get("TMPDIR", "/tmp"))
+                cpu_baseline = {"value": round(info["msamples_per_s"], 4), "unit": "Msamples/s", "cores": info["threads"],
+                                "kind": "reference",
+                                "sample": f"03_volume {info['width']}x{info['height']}x{sspp}spp, reference renderer (g++ -O2)"}
+            else:
+                sp = vpt.PathtraceParams(resolution=sres, samples=1 << 30, shader=args.shader, bounces=args.bounces)
+                sstate = scene.make_state(sp)
+                t1 = time.perf_counter()
+                oracle_lib.oracle_render(scene, sp, sstate, sspp, nthreads=0)
+                dt = time.perf_counter() - t1
+                cpu_baseline = {"value": round(sstate.width * sstate.height * sspp / dt * 1e-6, 4), "unit": "Msamples/s",
+                                "cores": ncores, "kind": "port",
+                                "sample": f"03_volume {sstate.width}x{sstate.height}x{sspp}spp, oracle/vpt_oracle.cpp"}
+        line = {
+            "metric": "Msamples/sec", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "reference scene tests/03_volume (real assets), deterministic PCG32 seeds",
+            "config": {"workload": f"03_volume {args.shader} bounces={args.bounces} {width}x{height}x{args.spp}spp per step",
+                       "tile": f"{args.tile}x{args.tile}", "parallelism": f"tiles%{world}" if world > 1 else "1gpu",
+                       "samples_per_step": samples_per_step},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Regenerates the golden vectors under tests/golden/ by running the REFERENCE'S OWN renderer
+(oracle/_ref/ref_driver, built from /root/reference by oracle/Makefile).  Run in the build
+container only; the outputs (data: float32 states, stats, one JPEG) are committed so that the
+tests can pin the oracle and the host pipeline on machines where the reference does not exist.
+
+    python tests/golden/make_fixtures.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+
+REF_SCENE = "/root/reference/tests/03_volume/volume.json"
+
+# (name, shader, resolution, samples, bounces)
+CASES = [
+    ("vol_64_1", "volpathtrace", 64, 1, 64),      # samples==1: pixel-centre preview branch
+    ("vol_64_4", "volpathtrace", 64, 4, 64),
+    ("vol_96_16", "volpathtrace", 96, 16, 64),
+    ("path_64_4", "pathtrace", 64, 4, 4),
+    ("naive_64_4", "naive", 64, 4, 4),
+    ("eye_64_2", "eyelight", 64, 2, 4),
+    ("normal_64_2", "normal", 64, 2, 4),
+    ("texcoord_64_2", "texcoord", 64, 2, 4),
+    ("color_64_2", "color", 64, 2, 4),
+]
+
+
+def main():
+    assert O.have_reference(), "build oracle/_ref first: make -C oracle ref"
+    out = {}
+    for name, shader, res, spp, bounces in CASES:
+        w, h, image, hits, rngs, info = O.reference_render(REF_SCENE, shader, res, spp, bounces)
+        out[name + "_image"] = image
+        out[name + "_rngs"] = rngs
+        out[name + "_meta"] = np.array([w, h, spp, bounces], np.int32)
+        print(name, w, h)
+    np.savez_compressed(os.path.join(HERE, "03_volume_states.npz"), **out)
+    # structural statistics + hashes of the reference's scene / bvh / lights
+    *_, stats = O.reference_render(REF_SCENE, "volpathtrace", 64, 1, 4, stats=True)
+    stats.pop("state")
+    json.dump(stats, open(os.path.join(HERE, "03_volume_stats.json"), "w"), indent=1)
+    # the reference's own JPEG of a small render + the state it was made from
+    jpg = os.path.join(HERE, "03_volume_128_8.jpg")
+    w, h, image, hits, rngs, info = O.reference_render(REF_SCENE, "volpathtrace", 128, 8, 64, output=jpg)
+    np.savez_compressed(os.path.join(HERE, "03_volume_128_8_state.npz"), image=image, meta=np.array([w, h, 8], np.int32))
+    print("jpeg", w, h, os.path.getsize(jpg))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,198 @@
+"""GPU parity tests (run on a real MI355X with -m gpu).  Everything goes through the C-ABI of
+libvpt_hip.so; the CPU oracle is only the checker.
+
+Tolerance model.  Integer work (PCG32 streams, hit counts) must be bit-exact.  Radiance is float32
+computed with the reference's operation order, but device libm (ocml sinf/cosf/logf/expf/powf/
+atan2f/acosf, <= 2 ulp) is not glibc's, so a small fraction of paths takes a different discrete
+decision somewhere (a Fresnel coin, a russian-roulette test, a silhouette hit) and that pixel's
+stream diverges from then on.  The tests therefore require (a) a large majority of pixels to end with
+the oracle's exact RNG state, (b) those pixels to agree to 1e-3 relative, and (c) whole-image
+statistics to agree within Monte-Carlo error.  Against the instructor images the bar is BASELINE's:
+per-channel RMS <= 2e-3 after the reference's sRGB8 + JPEG q75 stage."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+SHADERS = [("volpathtrace", 64, 4, 64), ("volpathtrace", 96, 16, 64), ("pathtrace", 64, 4, 4), ("naive", 64, 4, 4),
+           ("eyelight", 64, 2, 4), ("normal", 64, 2, 4), ("texcoord", 64, 2, 4), ("color", 64, 2, 4)]
+
+
+def _pair(vpt, scene, dev, oracle, shader, res, spp, bounces, total=None):
+    p = vpt.PathtraceParams(resolution=res, samples=total or spp, shader=shader, bounces=bounces)
+    g = scene.make_state(p)
+    c = g.copy()
+    dev.pathtrace_samples(g, p, spp)
+    oracle.oracle_render(scene, p, c, spp)
+    return g, c
+
+
+@pytest.mark.parametrize("shader,res,spp,bounces", SHADERS)
+def test_gpu_matches_oracle_small(vpt, scene03, dev03, oracle, shader, res, spp, bounces):
+    g, c = _pair(vpt, scene03, dev03, oracle, shader, res, spp, bounces)
+    assert g.samples == c.samples == spp
+    assert np.array_equal(g.hits, c.hits)                       # integer: exact
+    same = np.all(g.rngs == c.rngs, axis=-1)                    # pixels that replayed the oracle's paths
+    assert same.mean() >= 0.97, f"only {same.mean():.3f} of the pixel streams match the oracle"
+    a, b = g.image[same], c.image[same]
+    assert np.allclose(a, b, rtol=1e-3, atol=1e-4 * spp), float(np.abs(a - b).max())
+    # image-level agreement including the diverged pixels
+    assert abs(g.image[..., :3].mean() - c.image[..., :3].mean()) <= 0.02 * c.image[..., :3].mean() + 1e-6
+
+
+def test_gpu_matches_reference_fixtures(vpt, scene03, dev03):
+    """Same check directly against float32 states of the reference's own renderer."""
+    gold = np.load(os.path.join(GOLDEN, "03_volume_states.npz"))
+    p = vpt.PathtraceParams(resolution=96, samples=16, shader="volpathtrace", bounces=64)
+    g = scene03.make_state(p)
+    dev03.pathtrace_samples(g, p, 16)
+    same = np.all(g.rngs == gold["vol_96_16_rngs"], axis=-1)
+    assert same.mean() >= 0.97
+    assert np.allclose(g.image[same], gold["vol_96_16_image"][same], rtol=1e-3, atol=2e-3)
+
+
+def test_preview_branch_samples_equal_one(vpt, scene03, dev03):
+    """params.samples == 1: pixel centres, no jitter draws (yocto_pathtrace.cpp:1059-1068)"""
+    gold = np.load(os.path.join(GOLDEN, "03_volume_states.npz"))
+    p = vpt.PathtraceParams(resolution=64, samples=1, shader="volpathtrace", bounces=64)
+    g = scene03.make_state(p)
+    dev03.pathtrace_samples(g, p, 1)
+    same = np.all(g.rngs == gold["vol_64_1_rngs"], axis=-1)
+    assert same.mean() >= 0.97 and np.allclose(g.image[same], gold["vol_64_1_image"][same], rtol=1e-3, atol=1e-4)
+
+
+def test_batching_and_sample_cap(vpt, scene03, dev03):
+    """nsamples batching is an extension: result must equal consecutive single calls, bit for bit;
+    the call is a no-op once state.samples >= params.samples (cpp:1055)."""
+    p = vpt.PathtraceParams(resolution=64, samples=5, shader="volpathtrace", bounces=64)
+    a, b = scene03.make_state(p), scene03.make_state(p)
+    dev03.pathtrace_samples(a, p, 8)           # capped at 5
+    for _ in range(7):
+        dev03.pathtrace_samples(b, p, 1)
+    assert a.samples == b.samples == 5 and (a.hits == 5).all()
+    assert np.array_equal(a.image.view(np.uint32), b.image.view(np.uint32)) and np.array_equal(a.rngs, b.rngs)
+
+
+def test_run_to_run_determinism(vpt, scene03, dev03):
+    p = vpt.PathtraceParams(resolution=128, samples=8, shader="volpathtrace", bounces=64)
+    a, b = scene03.make_state(p), scene03.make_state(p)
+    dev03.pathtrace_samples(a, p, 8)
+    dev03.pathtrace_samples(b, p, 8)
+    assert np.array_equal(a.image.view(np.uint32), b.image.view(np.uint32)) and np.array_equal(a.rngs, b.rngs)
+
+
+def test_resume_across_backends(vpt, scene03, dev03, oracle):
+    """pathtrace_state is a resumable checkpoint: 2 passes on the GPU then 2 on the CPU
+    oracle ends (for pixels whose streams agree) where 4 oracle passes end."""
+    p = vpt.PathtraceParams(resolution=64, samples=4, shader="volpathtrace", bounces=64)
+    mixed, pure = scene03.make_state(p), scene03.make_state(p)
+    dev03.pathtrace_samples(mixed, p, 2)
+    oracle.oracle_render(scene03, p, mixed, 2)
+    oracle.oracle_render(scene03, p, pure, 4)
+    same = np.all(mixed.rngs == pure.rngs, axis=-1)
+    assert same.mean() >= 0.97 and np.allclose(mixed.image[same], pure.image[same], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("nranks,tile", [(2, 8), (4, 16), (8, 8)])
+def test_virtual_ranks_on_one_gpu_are_bit_identical(vpt, scene03, dev03, nranks, tile):
+    """The N-GPU image must equal the 1-GPU image bit for bit: run the N ranks'
+    launches one after another on this GPU through the device-state API, concatenate their tile
+    buffers as all_gather would, resolve, compare."""
+    import torch
+    p = vpt.PathtraceParams(resolution=200, samples=1 << 20, shader="volpathtrace", bounces=64)
+    host = scene03.make_state(p)
+    spp = 3
+    ref = host.copy()
+    dev03.pathtrace_samples(ref, p, spp)
+    dev = torch.device("cuda", 0)
+    parts = []
+    slots = vpt.layout_slots(vpt.VptLayout(host.width, host.height, tile, tile, 0, nranks))
+    for r in range(nranks):
+        lay = vpt.VptLayout(host.width, host.height, tile, tile, r, nranks)
+        img = torch.zeros((slots, 4), dtype=torch.float32, device=dev)
+        hit = torch.zeros((slots,), dtype=torch.int32, device=dev)
+        rng = torch.zeros((slots, 2), dtype=torch.int64, device=dev)
+        vpt.state_upload(lay, host, img.data_ptr(), hit.data_ptr(), rng.data_ptr())
+        dev03.render_device(p, lay, spp, img.data_ptr(), hit.data_ptr(), rng.data_ptr(), 0)
+        torch.cuda.synchronize()
+        # host mirror of the slot map agrees with the device permutation
+        idx = vpt.layout_pixel_index(lay)
+        back = host.copy()
+        vpt.state_download(lay, img.data_ptr(), hit.data_ptr(), rng.data_ptr(), back)
+        mine = idx[idx >= 0]
+        assert np.array_equal(back.image.reshape(-1, 4)[mine].view(np.uint32), ref.image.reshape(-1, 4)[mine].view(np.uint32))
+        assert np.array_equal(back.rngs.reshape(-1, 2)[mine], ref.rngs.reshape(-1, 2)[mine])
+        parts.append(img)
+    gathered = torch.cat(parts, 0)
+    frame = torch.zeros((host.height, host.width, 4), dtype=torch.float32, device=dev)
+    vpt.resolve_device(vpt.VptLayout(host.width, host.height, tile, tile, 0, nranks), gathered.data_ptr(), spp, frame.data_ptr())
+    torch.cuda.synchronize()
+    expect = ref.image * np.float32(np.float32(1) / np.float32(spp))
+    assert np.array_equal(frame.cpu().numpy().view(np.uint32), expect.view(np.uint32))
+
+
+def test_full_size_properties(vpt, scene03, dev03, oracle):
+    """BASELINE frame size 1280x533: size-independent properties + a low-res statistical cross-check."""
+    p = vpt.PathtraceParams(resolution=1280, samples=1 << 20, shader="volpathtrace", bounces=64)
+    g = scene03.make_state(p)
+    before = g.rngs.copy()
+    dev03.pathtrace_samples(g, p, 8)
+    assert (g.width, g.height, g.samples) == (1280, 533, 8)
+    assert (g.hits == 8).all() and np.isfinite(g.image).all() and (g.image >= 0).all()
+    assert (g.rngs[..., 1] == before[..., 1]).all() and (g.rngs[..., 0] != before[..., 0]).all()  # inc fixed, state moved
+    assert (g.image[..., 3] <= 8).all()                       # alpha accumulates 0/1 per sample
+    # same scene at 320 wide on the oracle: mean radiance within MC error
+    q = vpt.PathtraceParams(resolution=320, samples=1 << 20, shader="volpathtrace", bounces=64)
+    c = scene03.make_state(q)
+    oracle.oracle_render(scene03, q, c, 8)
+    assert abs(g.image[..., :3].mean() / c.image[..., :3].mean() - 1) < 0.03
+
+
+def _rms_vs_check(vpt, state, check_name):
+    from PIL import Image
+    jpg = vpt.encode_jpeg_q75(vpt.linear_to_srgb8(state.image, state.samples))
+    mine = np.asarray(Image.open(io.BytesIO(jpg)).convert("RGB"), np.float32) / 255
+    check = np.asarray(Image.open(os.path.join(GOLDEN, "check", check_name)).convert("RGB"), np.float32) / 255
+    assert mine.shape == check.shape
+    return np.sqrt(np.mean((mine - check) ** 2, axis=(0, 1)))
+
+
+def test_instructor_image_lowres(vpt, scene03, dev03):
+    """scripts/run.sh:3 — 720(x300) x 256 spp vs check/lowres (independent noise would be 0.059)"""
+    p = vpt.PathtraceParams(resolution=720, samples=256, shader="volpathtrace", bounces=64)
+    g = scene03.make_state(p)
+    dev03.pathtrace_samples(g, p, 256)
+    rms = _rms_vs_check(vpt, g, "03_volume_720_256.jpg")
+    print("lowres per-channel RMS", rms)
+    assert (rms <= 2e-3).all(), rms
+
+
+def test_instructor_image_highres_target(vpt, scene03, dev03):
+    """BASELINE target: tests/03_volume at 1280(x533) x 1024 spp within 2e-3 per-channel RMS of
+    check/highres (scripts/run-highres.sh:3); independent noise would be 0.030."""
+    p = vpt.PathtraceParams(resolution=1280, samples=1024, shader="volpathtrace", bounces=64)
+    g = scene03.make_state(p)
+    dev03.pathtrace_samples(g, p, 1024)
+    rms = _rms_vs_check(vpt, g, "03_volume_1280_1024.jpg")
+    print("highres per-channel RMS", rms)
+    assert (rms <= 2e-3).all(), rms
+
+
+def test_device_errors(vpt, scene03, dev03):
+    import ctypes as C
+    abi = vpt.PathtraceParams(shader="volpathtrace").to_abi()
+    abi.shader = 42
+    st = scene03.make_state(vpt.PathtraceParams(resolution=64))
+    n = C.c_int(0)
+    rc = vpt.hip.vpt_render(dev03.handle, C.byref(abi), 1, st.width, st.height, st.image.ctypes.data, st.hits.ctypes.data,
+                            st.rngs.ctypes.data, C.byref(n))
+    assert rc == -4 and b"sampler unknown" in vpt.hip.vpt_last_error()
+    abi.shader, abi.camera = 0, 7
+    rc = vpt.hip.vpt_render(dev03.handle, C.byref(abi), 1, st.width, st.height, st.image.ctypes.data, st.hits.ctypes.data,
+                            st.rngs.ctypes.data, C.byref(n))
+    assert rc == -1

@@ -250,3 +250,25 @@ def encode_jpeg_q75(rgba8: np.ndarray) -> bytes:
     buf = (C.c_uint8 * n)()
     host.vpth_encode_jpeg_q75(w, h, src.ctypes.data, buf, n)
     return bytes(buf)
+
+
+def layout_pixel_index(layout: VptLayout) -> np.ndarray:
+    """Host mirror of the device's slot -> pixel map (slot_to_pixel, csrc/vpt_kernels.hip.h): for every
+    state slot of `layout.rank`, the row-major pixel index j*width+i it holds, or -1 for padding."""
+    tw, th, w, h = layout.tile_w, layout.tile_h, layout.width, layout.height
+    if tw % 8 or th % 8 or tw < 8 or th < 8:
+        raise VptError("tile size must be a multiple of 8x8")
+    tiles_x, tiles_y = -(-w // tw), -(-h // th)
+    per_tile = tw * th
+    local_tiles = -(-(tiles_x * tiles_y) // layout.nranks)
+    slot = np.arange(local_tiles * per_tile, dtype=np.int64)
+    local_tile, p = slot // per_tile, slot % per_tile
+    tile = local_tile * layout.nranks + layout.rank
+    ty, tx = tile // tiles_x, tile % tiles_x
+    bw = tw // 8
+    blk, q = p // 64, p % 64
+    by, bx = blk // bw, blk % bw
+    px = tx * tw + bx * 8 + (q % 8)
+    py = ty * th + by * 8 + (q // 8)
+    ok = (tile < tiles_x * tiles_y) & (px < w) & (py < h)
+    return np.where(ok, py * w + px, -1)

@@ -33,7 +33,8 @@ def _lib(name: str) -> C.CDLL:
     return C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
-hip = _lib("libvpt_hip.so")    # must load first: libvpt_host.so links against it
+hip = _lib(os.environ.get("VPT_HIP_LIB", "libvpt_hip.so"))    # must load first: libvpt_host.so links against it
+# (VPT_HIP_LIB selects an alternative build of the same ABI for A/B experiments)
 host = _lib("libvpt_host.so")
 
 

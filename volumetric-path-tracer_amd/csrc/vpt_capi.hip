@@ -10,7 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "vpt_kernels.hip.h"
+#include "vpt_mesh_kernel.hip.h"
 
 namespace {
 
@@ -55,6 +55,32 @@ void pack_frame(const hframe& f, float4* out) {
   out[0] = make_float4(f.x.x, f.x.y, f.x.z, f.y.x);
   out[1] = make_float4(f.y.y, f.y.z, f.z.x, f.z.y);
   out[2] = make_float4(f.z.z, f.o.x, f.o.y, f.o.z);
+}
+
+// Wide nodes (vpt_device.h): one 64-byte record per internal node with both child boxes + refs.
+// Returns the reference of the root and its box; appends to `out`; refs are relative to this BVH.
+int build_wide_nodes(const vpt_bvh_node* nodes, int count, std::vector<float4>& out, float root_box[6]) {
+  for (int k = 0; k < 6; k++) root_box[k] = 0;
+  if (count <= 0) return ~0;   // empty leaf
+  std::vector<int> wide_index((size_t)count, -1);
+  int nwide = 0;
+  for (int i = 0; i < count; i++)
+    if (nodes[i].internal) wide_index[(size_t)i] = nwide++;
+  auto ref_of = [&](int i) { return nodes[i].internal ? wide_index[(size_t)i] : ~((nodes[i].start << 4) | (nodes[i].num & 15)); };
+  size_t base = out.size();
+  out.resize(base + 4 * (size_t)nwide);
+  for (int i = 0; i < count; i++) {
+    if (!nodes[i].internal) continue;
+    const vpt_bvh_node &a = nodes[nodes[i].start], &b = nodes[nodes[i].start + 1];
+    float4* q = &out[base + 4 * (size_t)wide_index[(size_t)i]];
+    q[0] = make_float4(a.bbox_min[0], a.bbox_min[1], a.bbox_min[2], a.bbox_max[0]);
+    q[1] = make_float4(a.bbox_max[1], a.bbox_max[2], b.bbox_min[0], b.bbox_min[1]);
+    q[2] = make_float4(b.bbox_min[2], b.bbox_max[0], b.bbox_max[1], b.bbox_max[2]);
+    int meta[4] = {ref_of(nodes[i].start), ref_of(nodes[i].start + 1), nodes[i].axis, 0};
+    memcpy(&q[3], meta, 16);
+  }
+  for (int k = 0; k < 3; k++) root_box[k] = nodes[0].bbox_min[k], root_box[3 + k] = nodes[0].bbox_max[k];
+  return ref_of(0);
 }
 
 int bvh_depth(const vpt_bvh_node* nodes, int count, int root, int depth, int limit) {
@@ -107,7 +133,7 @@ int check_nodes(const vpt_bvh_node* nodes, long long count, long long nprims, co
   for (long long i = 0; i < count; i++) {
     const vpt_bvh_node& n = nodes[i];
     if (n.internal) REQUIRE(n.start > i && (long long)n.start + 1 < count, "%s bvh node %lld: bad children", what, i);
-    else REQUIRE(n.start >= 0 && n.num >= 0 && (long long)n.start + n.num <= nprims, "%s bvh node %lld: bad leaf range", what, i);
+    else REQUIRE(n.start >= 0 && n.num >= 0 && n.num <= 15 && n.start < (1 << 27) && (long long)n.start + n.num <= nprims, "%s bvh node %lld: bad leaf range", what, i);
     REQUIRE(n.axis >= 0 && n.axis <= 2, "%s bvh node %lld: bad axis", what, i);
   }
   return VPT_OK;
@@ -276,7 +302,7 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
 
   std::vector<DShape> shapes((size_t)d.num_shapes);
   std::vector<int4>   elems;
-  std::vector<float4> leafs;
+  std::vector<float4> leafs, shape_wnodes, scene_wnodes;
   int max_shape_depth = 0;
   for (int i = 0; i < d.num_shapes; i++) {
     const vpt_shape& sh = d.shapes[i];
@@ -309,15 +335,23 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
         leafs.push_back(p);
       }
     }
+    o.wnode_offset = (int)(shape_wnodes.size() / 4);
+    o.root_ref     = build_wide_nodes(d.shape_bvh_nodes + sh.bvh_node_offset, sh.num_bvh_nodes, shape_wnodes, o.root_box);
     int depth = o.num_nodes ? bvh_depth(d.shape_bvh_nodes + sh.bvh_node_offset, sh.num_bvh_nodes, 0, 0, 4096) : 0;
     o.stack_need = depth + 2;
     if (depth > max_shape_depth) max_shape_depth = depth;
   }
   int scene_depth = d.num_scene_bvh_nodes ? bvh_depth(d.scene_bvh_nodes, d.num_scene_bvh_nodes, 0, 0, 4096) : 0;
+  float scene_box[6];
+  D.scene_root_ref = build_wide_nodes(d.scene_bvh_nodes, d.num_scene_bvh_nodes, scene_wnodes, scene_box);
+  D.scene_root_lo_x = scene_box[0], D.scene_root_lo_y = scene_box[1], D.scene_root_lo_z = scene_box[2];
+  D.scene_root_hi_x = scene_box[3], D.scene_root_hi_y = scene_box[4], D.scene_root_hi_z = scene_box[5];
+  // stack entries alive at once: one pending sibling per level (+ the two just pushed), scene level
+  // entries stay below the entries of the instance being traversed
   int need = (scene_depth + 2) + (max_shape_depth + 2);
-  s->stack_cap = ((need > 16 ? need : 16) + 7) & ~7;
-  if ((size_t)s->stack_cap * VPT_BLOCK * sizeof(int) > 64 * 1024)
-    return fail(VPT_ERR_UNSUPPORTED, "BVH depth %d needs a %d-entry traversal stack; the LDS stack holds 64", need, s->stack_cap);
+  s->stack_cap = ((need > 8 ? need : 8) + 3) & ~3;
+  if ((size_t)s->stack_cap * 2 * VPT_BLOCK * sizeof(int) > 64 * 1024)
+    return fail(VPT_ERR_UNSUPPORTED, "BVH depth %d needs a %d-entry traversal stack; the LDS stack holds 32", need, s->stack_cap);
 
   std::vector<DInstance> instances((size_t)d.num_instances);
   for (int i = 0; i < d.num_instances; i++) {
@@ -344,6 +378,8 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   UP(upload(s, d.scene_bvh_prims, d.num_scene_bvh_prims, &D.scene_prims));
   UP(upload(s, (const float4*)d.shape_bvh_nodes, 2LL * d.num_shape_bvh_nodes, &D.shape_nodes));
   UP(upload(s, leafs, &D.leaf_prims));
+  UP(upload(s, scene_wnodes, &D.scene_wnodes));
+  UP(upload(s, shape_wnodes, &D.shape_wnodes));
   UP(upload(s, instances, &D.instances));
   UP(upload(s, shapes, &D.shapes));
   UP(upload(s, elems, &D.elems));
@@ -449,24 +485,27 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
   dim3   grid((pr.nslots + VPT_BLOCK - 1) / VPT_BLOCK), block(VPT_BLOCK);
-  size_t lds = (size_t)s->stack_cap * VPT_BLOCK * sizeof(int);
+  size_t lds  = (size_t)s->stack_cap * VPT_BLOCK * sizeof(int);       // implicit kernels: refs only
+  size_t lds2 = (size_t)s->stack_cap * 2 * VPT_BLOCK * sizeof(int);   // mesh kernel: (ref, t0) pairs
   auto   img = (float4*)d_image;
   auto   hit = (int*)d_hits;
   auto   rng = (ulonglong2*)d_rng;
   HIP_TRY(hipEventRecord(s->ev0, st));
 #define LAUNCH(K) hipLaunchKernelGGL(vpt_render_kernel<K>, grid, block, lds, st, s->d, pr, img, hit, rng, s->stack_cap)
+#define LAUNCH_MESH(K) hipLaunchKernelGGL(vpt_mesh_kernel<K>, grid, block, lds2, st, s->d, pr, img, hit, rng, s->stack_cap)
   switch (params->shader) {
-    case VPT_SHADER_VOLPATHTRACE: LAUNCH(K_VOLPATH); break;
-    case VPT_SHADER_PATHTRACE: LAUNCH(K_PATH); break;
-    case VPT_SHADER_NAIVE: LAUNCH(K_NAIVE); break;
-    case VPT_SHADER_EYELIGHT: LAUNCH(K_EYELIGHT); break;
+    case VPT_SHADER_VOLPATHTRACE: LAUNCH_MESH(K_VOLPATH); break;
+    case VPT_SHADER_PATHTRACE: LAUNCH_MESH(K_PATH); break;
+    case VPT_SHADER_NAIVE: LAUNCH_MESH(K_NAIVE); break;
+    case VPT_SHADER_EYELIGHT: LAUNCH_MESH(K_EYELIGHT); break;
     case VPT_SHADER_NORMAL:
     case VPT_SHADER_TEXCOORD:
-    case VPT_SHADER_COLOR: LAUNCH(K_DEBUG); break;
+    case VPT_SHADER_COLOR: LAUNCH_MESH(K_DEBUG); break;
     case VPT_SHADER_IMPLICIT: LAUNCH(K_IMPLICIT); break;
     case VPT_SHADER_IMPLICIT_NORMAL: LAUNCH(K_IMPLICIT_NORMAL); break;
   }
 #undef LAUNCH
+#undef LAUNCH_MESH
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev1, st));
   s->timed = true;

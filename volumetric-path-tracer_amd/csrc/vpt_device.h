@@ -26,7 +26,7 @@ struct DInstance {       // 128 B
 };
 // A frame {x,y,z,o} (4 columns of 3) packed in 3 float4: {x.x,x.y,x.z,y.x} {y.y,y.z,z.x,z.y} {z.z,o.x,o.y,o.z}
 
-struct DShape {          // 48 B
+struct DShape {          // 80 B
   int num_nodes, node_offset;  // into shape_nodes (in nodes)
   int leaf_offset;             // into leaf_prims (in records), slot = leaf_offset + node.start + k
   int is_triangles;            // shape.triangles non-empty (reference tests triangles first)
@@ -35,7 +35,10 @@ struct DShape {          // 48 B
   int normal_offset, texcoord_offset, color_offset;  // -1 if absent
   int num_elems;
   int stack_need;              // max traversal stack depth for this shape's BVH
-  int pad;
+  int root_ref;                // wide-node reference of the BVH root (see DScene::shape_wnodes)
+  int wnode_offset;            // into shape_wnodes (in wide nodes)
+  float root_box[6];           // bbox of the root: the reference tests it at the first pop
+  int pad2;
 };
 
 struct DScene {
@@ -47,6 +50,14 @@ struct DScene {
   const int*    scene_prims;
   const float4* shape_nodes;   // 2 per node, pooled
   const float4* leaf_prims;    // 4 per slot, pooled
+  // "wide" nodes for the unified traversal: one 64-byte record per INTERNAL node holding BOTH child
+  // boxes and child references, so a visit costs one fetch and culled children are never fetched.
+  //   q0 = {L.min.xyz, L.max.x} q1 = {L.max.yz, R.min.xy} q2 = {R.min.z, R.max.xyz}
+  //   q3 = {ref0, ref1, axis, -} (ints); ref >= 0: internal wide node; ref < 0: leaf, ~ref = start<<4 | num
+  const float4* scene_wnodes;
+  const float4* shape_wnodes;
+  int   scene_root_ref, pad1;
+  float scene_root_lo_x, scene_root_lo_y, scene_root_lo_z, scene_root_hi_x, scene_root_hi_y, scene_root_hi_z;
   // geometry
   const DInstance* instances;
   const DShape*    shapes;

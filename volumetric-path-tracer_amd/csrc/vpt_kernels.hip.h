@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) vpt_render_kernel(DScene sc, DParam
   f4         acc    = mk4(acc_in.x, acc_in.y, acc_in.z, acc_in.w);
   ulonglong2 r_in   = rngs[slot];
   rng_t      rng    = {r_in.x, r_in.y};
-  const vpt_camera cam = sc.cameras[pr.camera];
+  const vpt_camera& cam = sc.cameras[pr.camera];
   const int nb = (SH == K_EYELIGHT) ? max(pr.bounces, 4) : pr.bounces;
 
   // ---- path state --------------------------------------------------------------------------------

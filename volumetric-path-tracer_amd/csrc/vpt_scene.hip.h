@@ -167,7 +167,7 @@ VPT_DEV f4 lookup_texture(const DScene& sc, const vpt_texture& t, int i, int j, 
 }
 VPT_DEV f4 eval_texture(const DScene& sc, int texture, f2 uv, bool as_linear) {
   if (texture == VPT_INVALID) return mk4(1, 1, 1, 1);
-  vpt_texture t = sc.textures[texture];
+  const vpt_texture& t = sc.textures[texture];
   if (t.width == 0 || t.height == 0) return mk4(0, 0, 0, 0);
   float s = fmodf(uv.x, 1.0f) * t.width;
   if (s < 0) s += t.width;
@@ -255,7 +255,7 @@ VPT_DEV f4 eval_color(const DScene& sc, const DInstance& inst, int element, f2 u
   return tri_lerp(mk4(a.x, a.y, a.z, a.w), mk4(b.x, b.y, b.z, b.w), mk4(d.x, d.y, d.z, d.w), c.uv);
 }
 // normal mapping, yocto_scene.cpp:414-457 + yocto_geometry.h:606-640 (cold: only `normal_tex` materials)
-__device__ __noinline__ f3 eval_normalmap(const DScene& sc, const DInstance& inst, int element, f2 uv, f3 normal, int normal_tex) {
+VPT_DEV f3 eval_normalmap(const DScene& sc, const DInstance& inst, int element, f2 uv, f3 normal, int normal_tex) {
   const DShape& sh = sc.shapes[inst.shape];
   f2 texcoord  = eval_texcoord(sc, inst, element, uv);
   f3 normalmap = -1 + 2 * xyz(eval_texture(sc, normal_tex, texcoord, false));
@@ -318,7 +318,7 @@ VPT_DEV void finish_material(mpoint& p, float trdepth) {
   else if (p.roughness < VPT_MIN_ROUGHNESS) p.roughness = 0;
 }
 VPT_DEV mpoint eval_material(const DScene& sc, const DInstance& inst, int element, f2 uv) {
-  vpt_material m  = sc.materials[inst.material];
+  const vpt_material& m  = sc.materials[inst.material];
   f2 texcoord     = eval_texcoord(sc, inst, element, uv);
   f4 emission_tex = eval_texture(sc, m.emission_tex, texcoord, true);
   f4 color_shp    = eval_color(sc, inst, element, uv);
@@ -340,7 +340,7 @@ VPT_DEV mpoint eval_material(const DScene& sc, const DInstance& inst, int elemen
   return p;
 }
 VPT_DEV mpoint eval_material_plain(const DScene& sc, int mat) {   // yocto_scene.cpp:581-619
-  vpt_material m = sc.materials[mat];
+  const vpt_material& m = sc.materials[mat];
   mpoint p;
   p.type = m.type, p.emission = ld3(m.emission), p.color = ld3(m.color), p.opacity = m.opacity;
   p.metallic     = m.metallic;
@@ -360,7 +360,7 @@ VPT_DEV bool is_volumetric_type(int t) { return t == VPT_MAT_REFRACTIVE || t == 
 VPT_DEV f3 eval_environment(const DScene& sc, f3 direction) {
   f3 emission = mk3(0, 0, 0);
   for (int e = 0; e < sc.num_environments; e++) {
-    vpt_environment env = sc.environments[e];
+    const vpt_environment& env = sc.environments[e];
     f3 wl = transform_direction(load_frame(sc.env_inv + 3 * e), direction);
     f2 tc = mk2(atan2f(wl.z, wl.x) / (2 * VPT_PI), acosf(clampf(wl.y, -1.0f, 1.0f)) / VPT_PI);
     if (tc.x < 0) tc.x += 1;
@@ -855,7 +855,7 @@ VPT_DEV float eval_volume(const DScene& sc, const vpt_volume& vol, f3 uvw) {
          v111 * u * v * w;
 }
 VPT_DEV float eval_sdf_grid(const DScene& sc, const vpt_volume_instance& inst, f3 p, float t) {   // yocto_sdfs.cpp:30-49
-  vpt_volume vol = sc.volumes[inst.volume];
+  const vpt_volume& vol = sc.volumes[inst.volume];
   f3 grid_res = mk3((float)vol.whd[0], (float)vol.whd[1], (float)vol.whd[2]);
   f3 origin   = ld3(inst.frame.o);
   f3 bbox_max  = origin + (vol.res * grid_res) * inst.scalef;
@@ -871,12 +871,12 @@ struct sdf_hit { float result; int instance, sdf; };
 VPT_DEV sdf_hit eval_sdf_scene(const DScene& sc, f3 p, float t) {   // yocto_sdfs.cpp:7-26 (first minimum wins ties)
   sdf_hit res = {VPT_FLT_MAX, -1, -1};
   for (int idx = 0; idx < sc.num_vol_instances; idx++) {
-    vpt_volume_instance inst = sc.vol_instances[idx];
+    const vpt_volume_instance& inst = sc.vol_instances[idx];
     float d = eval_sdf_grid(sc, inst, transform_point(load_frame(inst.frame), p), t);
     if (d < res.result) res.result = d, res.instance = idx, res.sdf = -1;
   }
   for (int idx = 0; idx < sc.num_sdfs; idx++) {
-    vpt_sdf sdf = sc.sdfs[idx];
+    const vpt_sdf& sdf = sc.sdfs[idx];
     float d = eval_sdf_function(sdf, transform_point(load_frame(sdf.frame), p));
     if (d < res.result) res.result = d, res.instance = -1, res.sdf = idx;
   }
@@ -905,7 +905,7 @@ struct st_hit { bool hit; float dist; int instance, sdf; };
 VPT_DEV st_hit spheretrace_one(const DScene& sc, f3 ro, f3 rd, int sdf_handle, int maxiter) {   // cpp:267-286
   st_hit r = {false, VPT_FLT_MAX, -1, -1};
   float  t = VPT_RAY_EPS;
-  vpt_sdf sdf = sc.sdfs[sdf_handle];
+  const vpt_sdf& sdf = sc.sdfs[sdf_handle];
   frame  f   = load_frame(sdf.frame);
   for (int i = 0; i < maxiter && t < VPT_FLT_MAX; ++i) {
     float res = eval_sdf_function(sdf, transform_point(f, ro + rd * t));
@@ -936,7 +936,7 @@ VPT_DEV st_hit spheretrace(const DScene& sc, const ray_t& ray, int maxiter) {   
 // ------------------------------------------------------------------------------------------------
 VPT_DEV f3 sample_lights(const DScene& sc, f3 position, float rl, float rel, f2 ruv) {
   int       light_id = sample_uniform(sc.num_lights, rl);
-  vpt_light light    = sc.lights[light_id];
+  const vpt_light& light    = sc.lights[light_id];
   const float* cdf   = sc.light_cdf + light.cdf_offset;
   if (light.instance != VPT_INVALID) {
     const DInstance& inst = sc.instances[light.instance];
@@ -944,11 +944,11 @@ VPT_DEV f3 sample_lights(const DScene& sc, f3 position, float rl, float rel, f2 
     f2  uv      = sc.shapes[inst.shape].is_triangles ? mk2(1 - sqrtf(ruv.x), ruv.y * sqrtf(ruv.x)) : ruv;
     return normalize(eval_position(sc, inst, element, uv) - position);
   } else if (light.sdf != VPT_INVALID) {
-    vpt_sdf sdf = sc.sdfs[light.sdf];
+    const vpt_sdf& sdf = sc.sdfs[light.sdf];
     f3 wlightp  = transform_point(load_frame(sc.sdf_inv + 3 * light.sdf), mk3(ruv.x, ruv.y, 1) * ld3(sdf.whd));
     return normalize(wlightp - position);
   } else if (light.environment != VPT_INVALID) {
-    vpt_environment env = sc.environments[light.environment];
+    const vpt_environment& env = sc.environments[light.environment];
     if (env.emission_tex != VPT_INVALID) {
       int tw = sc.textures[env.emission_tex].width, th = sc.textures[env.emission_tex].height;
       int idx = sample_discrete(cdf, light.cdf_len, rel);
@@ -963,7 +963,7 @@ VPT_DEV f3 sample_lights(const DScene& sc, f3 position, float rl, float rel, f2 
 VPT_DEV float sample_lights_pdf(const DScene& sc, f3 position, f3 direction, int maxiter, const lane_stack& stk) {
   float pdf = 0.0f;
   for (int l = 0; l < sc.num_lights; l++) {
-    vpt_light    light = sc.lights[l];
+    const vpt_light&    light = sc.lights[l];
     const float* cdf   = sc.light_cdf + light.cdf_offset;
     if (light.instance != VPT_INVALID) {
       const DInstance& inst = sc.instances[light.instance];
@@ -988,7 +988,7 @@ VPT_DEV float sample_lights_pdf(const DScene& sc, f3 position, f3 direction, int
         pdf += distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * area);
       }
     } else if (light.environment != VPT_INVALID) {
-      vpt_environment env = sc.environments[light.environment];
+      const vpt_environment& env = sc.environments[light.environment];
       if (env.emission_tex != VPT_INVALID) {
         int tw = sc.textures[env.emission_tex].width, th = sc.textures[env.emission_tex].height;
         f3 wl = transform_direction(load_frame(sc.env_inv + 3 * light.environment), direction);

@@ -10,7 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "vpt_mesh_kernel.hip.h"
+#include "vpt_stream_kernels.hip.h"
 
 namespace {
 
@@ -104,6 +104,14 @@ struct vpt_scene {
   long long  staged_pixels = 0, staged_slots = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool       timed = false;
+  // streaming pipeline (vpt_stream_kernels.hip.h): path state + ray queues, sized for `path_slots`
+  DPaths     paths = {};
+  long long  path_slots = 0;
+  std::vector<void*> path_allocs;
+  int*       host_counts = nullptr;   // pinned, 2 ints
+  bool       large_mesh_lights = false;
+  long long  last_iterations = 0;
+  int        trace_blocks = 1024;     // resident workgroups of the persistent trace kernel
 };
 
 namespace {
@@ -269,6 +277,8 @@ void vpt_scene_destroy(vpt_scene* s) {
   for (void* p : s->allocs) (void)hipFree(p);
   for (void* p : {s->s_image, s->s_hits, s->s_rng, s->r_image, s->r_hits, s->r_rng})
     if (p) (void)hipFree(p);
+  for (void* p : s->path_allocs) (void)hipFree(p);
+  if (s->host_counts) (void)hipHostFree(s->host_counts);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -353,6 +363,8 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   if ((size_t)s->stack_cap * 2 * VPT_BLOCK * sizeof(int) > 64 * 1024)
     return fail(VPT_ERR_UNSUPPORTED, "BVH depth %d needs a %d-entry traversal stack; the LDS stack holds 32", need, s->stack_cap);
 
+  for (int i = 0; i < d.num_lights; i++)
+    if (d.lights[i].instance >= 0 && shapes[(size_t)d.instances[d.lights[i].instance].shape].root_ref >= 0) s->large_mesh_lights = true;
   std::vector<DInstance> instances((size_t)d.num_instances);
   for (int i = 0; i < d.num_instances; i++) {
     hframe f = to_h(d.instances[i].frame);
@@ -403,6 +415,15 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   UP(upload(s, sdf_inv, &D.sdf_inv));
   UP(upload(s, d.cameras, d.num_cameras, &D.cameras));
 #undef UP
+  {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    size_t lds_block = (size_t)s->stack_cap * 2 * VPT_BLOCK * sizeof(int);
+    int per_cu = (int)((160 * 1024) / (lds_block ? lds_block : 1));
+    if (per_cu > 4) per_cu = 4;   // __launch_bounds__(256, 4): 4 waves/SIMD = 4 workgroups/CU
+    if (per_cu < 1) per_cu = 1;
+    s->trace_blocks = prop.multiProcessorCount * per_cu;
+  }
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
   HIP_TRY(hipDeviceSynchronize());
@@ -473,6 +494,71 @@ int vpt_state_download(const vpt_layout* layout, const void* d_image, const void
   return rc;
 }
 
+}  // extern "C"
+
+static int ensure_paths(vpt_scene* s, long long nslots) {
+  if (s->path_slots == nslots) return VPT_OK;
+  for (void* p : s->path_allocs) (void)hipFree(p);
+  s->path_allocs.clear();
+  s->path_slots = 0;
+  auto alloc = [&](size_t bytes, void** out) -> int {
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
+    s->path_allocs.push_back(*out);
+    return VPT_OK;
+  };
+  size_t n = (size_t)nslots;
+  DPaths& P = s->paths;
+  int rc;
+#define PA(field, bytes) if ((rc = alloc((bytes), (void**)&P.field)) != VPT_OK) return rc
+  PA(ray_o, n * 16); PA(ray_d, n * 16); PA(weight, n * 16); PA(rad, n * 16); PA(med0, n * 16); PA(med1, n * 16);
+  PA(med2, n * 8); PA(hit, n * 16); PA(hit_t, n * 4); PA(queue[0], n * 4); PA(queue[1], n * 4); PA(count, 16);
+#undef PA
+  if (!s->host_counts) HIP_TRY(hipHostMalloc((void**)&s->host_counts, 16, hipHostMallocDefault));
+  s->path_slots = nslots;
+  return VPT_OK;
+}
+
+// The streaming form of K1: k_begin, then (k_trace, k_shade) pairs until every queue is empty.
+// Queue sizes only shrink, so the grid follows the last count read back (every 16 iterations).
+template <int K>
+static int render_stream(vpt_scene* s, const DParams& pr, float4* img, int* hit, ulonglong2* rng, hipStream_t st) {
+  if (int rc = ensure_paths(s, pr.nslots)) return rc;
+  const DPaths& P = s->paths;
+  size_t lds_trace = (size_t)s->stack_cap * 2 * VPT_BLOCK * sizeof(int);
+  size_t lds_shade = s->large_mesh_lights ? (size_t)s->stack_cap * VPT_BLOCK * sizeof(int) : 0;
+  HIP_TRY(hipMemsetAsync(P.count, 0, 16, st));
+  int blocks = (pr.nslots + VPT_BLOCK - 1) / VPT_BLOCK;
+  hipLaunchKernelGGL(vpt_stream_begin<K>, dim3(blocks), dim3(VPT_BLOCK), 0, st, s->d, pr, P, img, hit, rng);
+  HIP_TRY(hipGetLastError());
+  int q = 0;
+  long long upper = pr.nslots, it = 0;
+  while (upper > 0) {
+    int grid = (int)((upper + VPT_BLOCK - 1) / VPT_BLOCK);
+    hipLaunchKernelGGL(vpt_stream_trace, dim3(grid), dim3(VPT_BLOCK), lds_trace, st, s->d, P, q, s->stack_cap);
+    hipLaunchKernelGGL(vpt_stream_shade<K>, dim3(grid), dim3(VPT_BLOCK), lds_shade, st, s->d, pr, P, q, img, hit, rng, s->stack_cap);
+    q ^= 1;
+    if ((++it & 15) == 0) {
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(s->host_counts, P.count, 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      upper = s->host_counts[q];
+    }
+    if (it > (1LL << 24)) return fail(VPT_ERR_HIP, "streaming pipeline did not terminate");
+  }
+  s->last_iterations = it;
+  return VPT_OK;
+}
+
+static bool use_stream_pipeline() {
+  static int choice = [] {
+    const char* e = getenv("VPT_PIPELINE");
+    return (e && !strcmp(e, "stream")) ? 1 : 0;   // default: the single-kernel form (faster on MI355X)
+  }();
+  return choice != 0;
+}
+
+extern "C" {
+
 int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* layout, int nsamples, void* d_image,
     void* d_hits, void* d_rng, void* stream) {
   if (!s || !params || !layout || !d_image || !d_hits || !d_rng) return fail(VPT_ERR_INVALID_ARG, "null argument");
@@ -492,7 +578,14 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
   auto   rng = (ulonglong2*)d_rng;
   HIP_TRY(hipEventRecord(s->ev0, st));
 #define LAUNCH(K) hipLaunchKernelGGL(vpt_render_kernel<K>, grid, block, lds, st, s->d, pr, img, hit, rng, s->stack_cap)
-#define LAUNCH_MESH(K) hipLaunchKernelGGL(vpt_mesh_kernel<K>, grid, block, lds2, st, s->d, pr, img, hit, rng, s->stack_cap)
+#define LAUNCH_MESH(K)                                                                                          \
+  do {                                                                                                          \
+    if (use_stream_pipeline()) {                                                                                \
+      if (int rc_ = render_stream<K>(s, pr, img, hit, rng, st)) return rc_;                                     \
+    } else {                                                                                                    \
+      hipLaunchKernelGGL(vpt_mesh_kernel<K>, grid, block, lds2, st, s->d, pr, img, hit, rng, s->stack_cap);    \
+    }                                                                                                           \
+  } while (0)
   switch (params->shader) {
     case VPT_SHADER_VOLPATHTRACE: LAUNCH_MESH(K_VOLPATH); break;
     case VPT_SHADER_PATHTRACE: LAUNCH_MESH(K_PATH); break;

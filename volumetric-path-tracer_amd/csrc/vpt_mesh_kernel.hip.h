@@ -75,87 +75,133 @@ VPT_DEV bool has_zero(f3 d) { return d.x == 0 || d.y == 0 || d.z == 0; }
 
 // One BVH query.  only_instance < 0: intersect_bvh(bvh, scene, ray) (yocto_bvh.cpp:800-871);
 // only_instance >= 0: intersect_bvh(bvh, scene, instance, ray) (:874-881).  Ray = {wo, wd, 1e-4, flt_max}.
+//
+// Loop shape: the lane's next action is kept in `cur` (>= 0: internal wide node of the current level,
+// VPT_NONE: nothing left at this level, other negatives: a leaf).  Each trip of the outer loop runs up
+// to three phases, each entered only by the lanes that need it, so unlike work is never interleaved
+// inside one loop body:
+//   A  internal nodes: fetch, two box tests, descend into the first-visited child directly (it would
+//      be popped next with the same tmax, so its pop test is a tautology) and push the other one;
+//   B  shape leaf: primitive tests in order;
+//   C  scene leaf / pending instances: transform the ray, test the instance's root box (the test the
+//      reference's shape-level loop does first, yocto_bvh.cpp:728-733); instances that miss it are
+//      skipped without ever leaving world space.
+#define VPT_NONE (-2147483647 - 1)
 VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const lane_stack2& stk) {
   hit_t r;
   r.instance = -1, r.element = -1, r.uv = mk2(0, 0), r.distance = 0, r.hit = false;
   const float tmin = VPT_RAY_EPS;
   float tmax = VPT_FLT_MAX;
-  f3    co = wo, cd = wd, cinv = mk3(1 / wd.x, 1 / wd.y, 1 / wd.z);
-  int   csgn = sign_bits(cinv);
-  bool  slow = has_zero(cd);
-  int   sp = 0, shape_base = -1, pend = 0, cur_inst = -1, enter = only_instance;
+  const f3   winv = mk3(1 / wd.x, 1 / wd.y, 1 / wd.z);
+  const int  wsgn = sign_bits(winv);
+  const bool wslow = has_zero(wd);
+  f3    co = wo, cd = wd, cinv = winv;
+  int   csgn = wsgn;
+  bool  slow = wslow;
+  int   sp = 0, shape_base = -1, pend = 0, cur_inst = -1, cur = VPT_NONE;
   const float4* wn    = sc.scene_wnodes;
   const float4* leafs = sc.leaf_prims;
+
+  // pop entries of the current level until one passes the reference's pop-time box test
+  auto pop_valid = [&]() {
+    int base = shape_base >= 0 ? shape_base : 0;
+    while (sp > base) {
+      int   ref;
+      float t0;
+      stk.pop(sp, ref, t0);
+      if (t0 <= tmax * VPT_BOX_K) return ref;
+    }
+    return VPT_NONE;
+  };
+  // enter pending instances (pend = start<<4 | count) until one passes its root test; else pop
+  auto enter_next = [&]() {
+    while (pend & 15) {
+      int id = sc.scene_prims[pend >> 4];
+      pend += 15;
+      const DInstance& inst = sc.instances[id];
+      frame inv = unpack_frame(inst.inv[0], inst.inv[1], inst.inv[2]);
+      f3    lo = transform_point(inv, wo), ld = transform_vector(inv, wd);
+      f3    linv = mk3(1 / ld.x, 1 / ld.y, 1 / ld.z);
+      bool  lslow = has_zero(ld);
+      const DShape& sh = sc.shapes[inst.shape];
+      float t0;
+      if (sh.num_nodes && box_test(lslow, ld3(sh.root_box), ld3(sh.root_box + 3), lo, linv, tmin, tmax, t0)) {
+        co = lo, cd = ld, cinv = linv, csgn = sign_bits(linv), slow = lslow;
+        cur_inst = id, shape_base = sp;
+        wn    = sc.shape_wnodes + 4 * (long long)sh.wnode_offset;
+        leafs = sc.leaf_prims + 4 * (long long)sh.leaf_offset;
+        return sh.root_ref;
+      }
+    }
+    return pop_valid();
+  };
+
   if (only_instance < 0) {
     float t0;
     if (sc.num_scene_nodes && box_test(slow, mk3(sc.scene_root_lo_x, sc.scene_root_lo_y, sc.scene_root_lo_z),
                                   mk3(sc.scene_root_hi_x, sc.scene_root_hi_y, sc.scene_root_hi_z), co, cinv, tmin, tmax, t0))
-      stk.push(sp, sc.scene_root_ref, t0);
+      cur = sc.scene_root_ref;
+  } else {   // single-instance query: a one-entry "scene leaf"
+    const DInstance& inst = sc.instances[only_instance];
+    frame inv = unpack_frame(inst.inv[0], inst.inv[1], inst.inv[2]);
+    co = transform_point(inv, wo), cd = transform_vector(inv, wd);
+    cinv = mk3(1 / cd.x, 1 / cd.y, 1 / cd.z), csgn = sign_bits(cinv), slow = has_zero(cd);
+    const DShape& sh = sc.shapes[inst.shape];
+    cur_inst = only_instance, shape_base = 0;
+    wn    = sc.shape_wnodes + 4 * (long long)sh.wnode_offset;
+    leafs = sc.leaf_prims + 4 * (long long)sh.leaf_offset;
+    float t0;
+    if (sh.num_nodes && box_test(slow, ld3(sh.root_box), ld3(sh.root_box + 3), co, cinv, tmin, tmax, t0)) cur = sh.root_ref;
   }
+
   while (true) {
-    // ---- phase A: pop / box-test / enter instances until this lane holds a non-empty leaf or is done ----
-    int leaf = 0;
-    while (true) {
-      if (shape_base >= 0 && sp == shape_base) {   // instance exhausted: back to world space
-        shape_base = -1;
-        co = wo, cd = wd, cinv = mk3(1 / wd.x, 1 / wd.y, 1 / wd.z), csgn = sign_bits(cinv), slow = has_zero(cd);
-        wn = sc.scene_wnodes;
-      }
-      if (shape_base < 0) {
-        if (enter < 0 && (pend & 15)) enter = sc.scene_prims[pend >> 4], pend += 15;   // next instance of the leaf
-        if (enter >= 0) {   // transform_ray(inverse(frame, true), ray) keeps tmin/tmax (yocto_bvh.cpp:853-855)
-          const DInstance& inst = sc.instances[enter];
-          frame inv = unpack_frame(inst.inv[0], inst.inv[1], inst.inv[2]);
-          co = transform_point(inv, wo), cd = transform_vector(inv, wd);
-          cinv = mk3(1 / cd.x, 1 / cd.y, 1 / cd.z), csgn = sign_bits(cinv), slow = has_zero(cd);
-          const DShape& sh = sc.shapes[inst.shape];
-          cur_inst = enter, enter = -1, shape_base = sp;
-          wn    = sc.shape_wnodes + 4 * (long long)sh.wnode_offset;
-          leafs = sc.leaf_prims + 4 * (long long)sh.leaf_offset;
-          float t0;
-          if (sh.num_nodes && box_test(slow, ld3(sh.root_box), ld3(sh.root_box + 3), co, cinv, tmin, tmax, t0)) stk.push(sp, sh.root_ref, t0);
-          continue;
-        }
-        if (sp == 0) break;   // done (leaf == 0)
-      }
-      int   ref;
-      float t0;
-      stk.pop(sp, ref, t0);
-      if (!(t0 <= tmax * VPT_BOX_K)) continue;   // the reference's pop-time box test (see header)
-      if (ref >= 0) {
-        const float4* q = wn + 4 * (long long)ref;
-        float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-        int   ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y), axis = __float_as_int(q3.z);
-        float ta, tb;
-        bool  pa = box_test(slow, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), co, cinv, tmin, tmax, ta);
-        bool  pb = box_test(slow, mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), co, cinv, tmin, tmax, tb);
-        if ((csgn >> axis) & 1) {   // push child 0 then child 1: child 1 is visited first
-          if (pa) stk.push(sp, ref0, ta);
-          if (pb) stk.push(sp, ref1, tb);
-        } else {
-          if (pb) stk.push(sp, ref1, tb);
-          if (pa) stk.push(sp, ref0, ta);
-        }
-        continue;
-      }
-      int code = ~ref;
-      if (shape_base < 0) {
-        pend = code;   // scene leaf: its instances are entered one after another, in order
-        continue;
-      }
-      if (code & 15) {
-        leaf = code;
-        break;
+    // ---- phase A: internal nodes ---------------------------------------------------------------------
+    while (cur >= 0) {
+      const float4* q = wn + 4 * (long long)cur;
+      float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+      float  ta, tb;
+      bool   pa = box_test(slow, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), co, cinv, tmin, tmax, ta);
+      bool   pb = box_test(slow, mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), co, cinv, tmin, tmax, tb);
+      int    ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y), axis = __float_as_int(q3.z);
+      bool   one_first = (csgn >> axis) & 1;   // the reference pushes 0 then 1 => child 1 is visited first
+      int    first = one_first ? ref1 : ref0, second = one_first ? ref0 : ref1;
+      bool   pf = one_first ? pb : pa, ps = one_first ? pa : pb;
+      float  ts = one_first ? ta : tb;
+      if (pf) {
+        if (ps) stk.push(sp, second, ts);
+        cur = first;
+      } else if (ps) {
+        cur = second;
+      } else {
+        cur = pop_valid();
       }
     }
-    if ((leaf & 15) == 0) break;   // query finished
-    // ---- phase B: every lane that holds a leaf tests its primitives, in order ---------------------------
-    int start = leaf >> 4, num = leaf & 15;
-    for (int k = 0; k < num; k++) {
-      const float4* rec = leafs + 4 * (long long)(start + k);
-      float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-      if (intersect_quad(co, cd, tmin, tmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), r.uv, r.distance))
-        r.hit = true, r.element = __float_as_int(r0.w), r.instance = cur_inst, tmax = r.distance;
+    if (cur == VPT_NONE) {
+      if (shape_base < 0 || only_instance >= 0) break;   // nothing left: query finished
+      // leaving an instance: back to world space, then its leaf's next instance or the next scene entry
+      shape_base = -1;
+      co = wo, cd = wd, cinv = winv, csgn = wsgn, slow = wslow;
+      wn  = sc.scene_wnodes;
+      cur = enter_next();
+      if (cur == VPT_NONE && shape_base < 0) break;
+      continue;
+    }
+    int code = ~cur;
+    if (shape_base >= 0) {
+      // ---- phase B: primitives of a shape leaf, in order -------------------------------------------------
+      int start = code >> 4, num = code & 15;
+      for (int k = 0; k < num; k++) {
+        const float4* rec = leafs + 4 * (long long)(start + k);
+        float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        if (intersect_quad(co, cd, tmin, tmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), r.uv, r.distance))
+          r.hit = true, r.element = __float_as_int(r0.w), r.instance = cur_inst, tmax = r.distance;
+      }
+      cur = pop_valid();
+    } else {
+      // ---- phase C: a scene leaf: its instances are entered one after another, in order ---------------------
+      pend = code;
+      cur  = enter_next();
+      if (cur == VPT_NONE && shape_base < 0) break;
     }
   }
   return r;

@@ -18,6 +18,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402
 
 REF_SCENE = "/root/reference/tests/03_volume/volume.json"
+SCENES = os.path.join(HERE, "scenes")
+# substitute scenes for the configs whose assets are missing (tests/golden/make_scenes.py); the reference's
+# own loader and renderer read them from here.  (name, scene, shader, resolution, samples, bounces, noimplicitmis)
+EXTRA = [
+    ("surf_path_96_4", "01_surface_min/surface_min.json", "pathtrace", 96, 4, 4, False),
+    ("surf_normal_96_1", "01_surface_min/surface_min.json", "normal", 96, 2, 4, False),
+    ("surf_eye_96_2", "01_surface_min/surface_min.json", "eyelight", 96, 2, 4, False),
+    ("head_vol_96_4", "05_head1ss_sub/head1ss_sub.json", "volpathtrace", 96, 4, 64, False),
+    ("sdf_implicit_96_4", "06_gridsdf_synth/gridsdf_synth.json", "implicit", 96, 4, 4, False),
+    ("sdf_nomis_96_4", "06_gridsdf_synth/gridsdf_synth.json", "implicit", 96, 4, 4, True),
+    ("sdf_normal_96_2", "06_gridsdf_synth/gridsdf_synth.json", "implicit_normal", 96, 2, 4, False),
+]
 
 # (name, shader, resolution, samples, bounces)
 CASES = [
@@ -43,6 +55,19 @@ def main():
         out[name + "_meta"] = np.array([w, h, spp, bounces], np.int32)
         print(name, w, h)
     np.savez_compressed(os.path.join(HERE, "03_volume_states.npz"), **out)
+    out = {}
+    all_stats = {}
+    for name, scene, shader, res, spp, bounces, nomis in EXTRA:
+        path = os.path.join(SCENES, scene)
+        w, h, image, hits, rngs, info, stats = O.reference_render(path, shader, res, spp, bounces, noimplicitmis=nomis, stats=True)
+        out[name + "_image"] = image
+        out[name + "_rngs"] = rngs
+        out[name + "_meta"] = np.array([w, h, spp, bounces, int(nomis)], np.int32)
+        stats.pop("state")
+        all_stats[scene] = stats
+        print(name, w, h)
+    np.savez_compressed(os.path.join(HERE, "substitute_states.npz"), **out)
+    json.dump(all_stats, open(os.path.join(HERE, "substitute_stats.json"), "w"), indent=1)
     # structural statistics + hashes of the reference's scene / bvh / lights
     *_, stats = O.reference_render(REF_SCENE, "volpathtrace", 64, 1, 4, stats=True)
     stats.pop("state")

@@ -89,3 +89,44 @@ def test_oracle_reproduces_instructor_image_lowres(vpt, scene03, oracle):
     assert mine.shape == check.shape == (300, 720, 3)
     rms = np.sqrt(np.mean((mine - check) ** 2, axis=(0, 1)))
     assert (rms < 1.5e-3).all(), rms
+
+
+# ---- substitute scenes (tests/golden/make_scenes.py): glossy + normal maps (config 1), 144k-triangle mesh with
+# ---- two environments and rough subsurface refraction (config 3), voxel-SDF + analytic SDFs + SDF light (config 4)
+EXTRA = {  # name -> (scene, shader, resolution, samples, bounces, noimplicit_mis)
+    "surf_path_96_4": ("01_surface_min/surface_min.json", "pathtrace", 96, 4, 4, False),
+    "surf_normal_96_1": ("01_surface_min/surface_min.json", "normal", 96, 2, 4, False),
+    "surf_eye_96_2": ("01_surface_min/surface_min.json", "eyelight", 96, 2, 4, False),
+    "head_vol_96_4": ("05_head1ss_sub/head1ss_sub.json", "volpathtrace", 96, 4, 64, False),
+    "sdf_implicit_96_4": ("06_gridsdf_synth/gridsdf_synth.json", "implicit", 96, 4, 4, False),
+    "sdf_nomis_96_4": ("06_gridsdf_synth/gridsdf_synth.json", "implicit", 96, 4, 4, True),
+    "sdf_normal_96_2": ("06_gridsdf_synth/gridsdf_synth.json", "implicit_normal", 96, 2, 4, False),
+}
+
+
+@pytest.fixture(scope="module")
+def substitute_states():
+    return np.load(os.path.join(GOLDEN, "substitute_states.npz"))
+
+
+@pytest.mark.parametrize("name", sorted(EXTRA))
+def test_oracle_bit_identical_on_substitute_scenes(vpt, oracle, substitute_states, name):
+    scene_file, shader, res, spp, bounces, nomis = EXTRA[name]
+    scene = vpt.HostScene(os.path.join(GOLDEN, "scenes", scene_file))
+    p = vpt.PathtraceParams(resolution=res, samples=spp, shader=shader, bounces=bounces, noimplicit_mis=nomis)
+    st = scene.make_state(p)
+    oracle.oracle_render(scene, p, st, spp, nthreads=8)
+    assert np.array_equal(st.rngs, substitute_states[name + "_rngs"])
+    assert np.array_equal(st.image.view(np.uint32), substitute_states[name + "_image"].view(np.uint32))
+
+
+def test_host_pipeline_matches_reference_on_substitute_scenes(vpt):
+    """loader (PLY triangles, binary + text .sdf, shared HDR), BVH build on 144k triangles, light CDFs of two
+    environments / an SDF light: FNV hashes equal the reference's."""
+    import json
+    golden = json.load(open(os.path.join(GOLDEN, "substitute_stats.json")))
+    for scene_file, stats in golden.items():
+        mine = json.loads(vpt.HostScene(os.path.join(GOLDEN, "scenes", scene_file)).stats())
+        assert mine == stats, scene_file
+    assert golden["05_head1ss_sub/head1ss_sub.json"]["shapes"][0]["triangles"] == 144046
+    assert golden["06_gridsdf_synth/gridsdf_synth.json"]["volumes"][0]["whd"] == [48, 48, 48]

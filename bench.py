@@ -18,7 +18,7 @@ The JSON line carries, besides the driver's contract:
                 on the launch stream, against the 8 TB/s HBM peak.
   cpu_baseline  the reference's own renderer (oracle/_ref/ref_driver, "reference") or, where that
                 binary is absent, our CPU restatement ("port"), timed on this host's cores on a
-                bounded sample (default 640x267x8 spp) of the same workload.  Rank 0, N=1 only.
+                bounded sample (default 640x267x96 spp, ~10 s) of the same workload.  Rank 0, N=1 only.
 """
 import argparse
 import json
@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--shader", default="volpathtrace")
     ap.add_argument("--scene", default=SCENE)
     ap.add_argument("--strong", action="store_true", help="fixed 1280-wide frame for every N")
-    ap.add_argument("--cpu-sample", default="640x8", help="cpu baseline sample: <resolution>x<spp>; '0' disables")
+    ap.add_argument("--cpu-sample", default="640x96", help="cpu baseline sample: <resolution>x<spp>; '0' disables")
     ap.add_argument("--tile", type=int, default=8)
     args = ap.parse_args()
 
@@ -147,15 +147,23 @@ def main():
         achieved = bps * per_launch_samples / (mean_ms * 1e-3) * 1e-9
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "kernel": "vpt_render_kernel<%s>" % args.shader, "kernel_ms": round(mean_ms, 3),
+                    "kernel": "vpt_mesh_kernel<%s>" % args.shader, "kernel_ms": round(mean_ms, 3),
                     "algorithmic_bytes_per_sample": round(bps, 1)}
         if world == 1 and args.cpu_sample != "0":
             sres, sspp = (int(x) for x in args.cpu_sample.split("x"))
-            ncores = os.cpu_count() or 1
+            # cores this process may actually use (cgroup / affinity), not the machine's thread count
+            ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            try:  # cgroup v2 CPU quota ("<quota> <period>" or "max <period>")
+                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if quota != "max":
+                    ncores = max(1, min(ncores, int(int(quota) / int(period))))
+            except (OSError, ValueError):
+                pass
             if oracle_lib.have_reference():
                 *_, info = oracle_lib.reference_render(args.scene, args.shader, sres, sspp, args.bounces,
                                                        workdir=os.environ.get("TMPDIR", "/tmp"))
-                cpu_baseline = {"value": round(info["msamples_per_s"], 4), "unit": "Msamples/s", "cores": info["threads"],
+                cpu_baseline = {"value": round(info["msamples_per_s"], 4), "unit": "Msamples/s", "cores": min(ncores, info["threads"]),
+                                "threads_started": info["threads"],
                                 "kind": "reference",
                                 "sample": f"03_volume {info['width']}x{info['height']}x{sspp}spp, reference renderer (g++ -O2)"}
             else:

@@ -145,8 +145,14 @@ def main():
         per_launch_samples = samples_per_step / world
         mean_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         achieved = bps * per_launch_samples / (mean_ms * 1e-3) * 1e-9
+        # memory-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+        # runs of this same command); only quoted for the workload it was measured on
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_v5_hbm_traffic.json")
+        if os.path.exists(tfile) and args.scene == SCENE and args.shader == "volpathtrace" and args.bounces == 64:
+            traffic = round(json.load(open(tfile))["bytes_per_sample"] * per_launch_samples)
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel": "vpt_mesh_kernel<%s>" % args.shader, "kernel_ms": round(mean_ms, 3),
                     "algorithmic_bytes_per_sample": round(bps, 1)}
         if world == 1 and args.cpu_sample != "0":

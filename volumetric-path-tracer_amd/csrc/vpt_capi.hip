@@ -372,6 +372,8 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
     pack_frame(hinverse(f, true), instances[i].inv);
     pack_frame(f, instances[i].fwd);
     instances[i].shape = d.instances[i].shape, instances[i].material = d.instances[i].material;
+    instances[i].translation_only = f.x.x == 1 && f.x.y == 0 && f.x.z == 0 && f.y.x == 0 && f.y.y == 1 && f.y.z == 0 &&
+                                    f.z.x == 0 && f.z.y == 0 && f.z.z == 1;
   }
   std::vector<float4> env_inv((size_t)d.num_environments * 3), sdf_inv((size_t)d.num_sdfs * 3);
   for (int i = 0; i < d.num_environments; i++) pack_frame(hinverse(to_h(d.environments[i].frame), false), &env_inv[3 * (size_t)i]);

@@ -22,7 +22,8 @@ struct DInstance {       // 128 B
   float4 inv[3];         // inverse(frame, non_rigid=true): rows packed as x,y,z columns + o: see pack
   float4 fwd[3];
   int    shape, material;
-  int    pad[6];
+  int    translation_only;   // rotation part is exactly the identity: local direction == world direction
+  int    pad[5];
 };
 // A frame {x,y,z,o} (4 columns of 3) packed in 3 float4: {x.x,x.y,x.z,y.x} {y.y,y.z,z.x,z.y} {z.z,o.x,o.y,o.z}
 

@@ -119,10 +119,18 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
       int id = sc.scene_prims[pend >> 4];
       pend += 15;
       const DInstance& inst = sc.instances[id];
-      frame inv = unpack_frame(inst.inv[0], inst.inv[1], inst.inv[2]);
-      f3    lo = transform_point(inv, wo), ld = transform_vector(inv, wd);
-      f3    linv = mk3(1 / ld.x, 1 / ld.y, 1 / ld.z);
-      bool  lslow = has_zero(ld);
+      f3   lo, ld, linv;
+      bool lslow;
+      if (inst.translation_only && !wslow) {
+        // inverse frame = {I, -o}: 1*d + 0*d' + 0*d'' == d bit for bit when no component is zero, and
+        // ((1*o.x + 0*o.y) + 0*o.z) + t == o.x + t: skip the 3x3 product and the three divisions
+        float4 c = inst.inv[2];   // {z.z, o.x, o.y, o.z}
+        lo = mk3(wo.x + c.y, wo.y + c.z, wo.z + c.w), ld = wd, linv = winv, lslow = false;
+      } else {
+        frame inv = unpack_frame(inst.inv[0], inst.inv[1], inst.inv[2]);
+        lo = transform_point(inv, wo), ld = transform_vector(inv, wd);
+        linv = mk3(1 / ld.x, 1 / ld.y, 1 / ld.z), lslow = has_zero(ld);
+      }
       const DShape& sh = sc.shapes[inst.shape];
       float t0;
       if (sh.num_nodes && box_test(lslow, ld3(sh.root_box), ld3(sh.root_box + 3), lo, linv, tmin, tmax, t0)) {

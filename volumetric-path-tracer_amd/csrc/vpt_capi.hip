@@ -375,6 +375,21 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
     instances[i].translation_only = f.x.x == 1 && f.x.y == 0 && f.x.z == 0 && f.y.x == 0 && f.y.y == 1 && f.y.z == 0 &&
                                     f.z.x == 0 && f.z.y == 0 && f.z.z == 1;
   }
+  std::vector<float4> enter((size_t)d.num_scene_bvh_prims * 6);
+  std::vector<int>    slot_of((size_t)d.num_instances, -1);
+  for (int k = 0; k < d.num_scene_bvh_prims; k++) {
+    int id = d.scene_bvh_prims[k];
+    const DInstance& in = instances[(size_t)id];
+    const DShape&    sh = shapes[(size_t)in.shape];
+    float4* e = &enter[6 * (size_t)k];
+    e[0] = in.inv[0], e[1] = in.inv[1], e[2] = in.inv[2];
+    e[3] = make_float4(sh.root_box[0], sh.root_box[1], sh.root_box[2], sh.root_box[3]);
+    int tail[6] = {sh.root_ref, sh.wnode_offset, sh.leaf_offset, id, in.translation_only, sh.num_nodes};
+    e[4] = make_float4(sh.root_box[4], sh.root_box[5], 0, 0);
+    memcpy(&e[4].z, &tail[0], 8);
+    memcpy(&e[5], &tail[2], 16);
+    slot_of[(size_t)id] = k;
+  }
   std::vector<float4> env_inv((size_t)d.num_environments * 3), sdf_inv((size_t)d.num_sdfs * 3);
   for (int i = 0; i < d.num_environments; i++) pack_frame(hinverse(to_h(d.environments[i].frame), false), &env_inv[3 * (size_t)i]);
   for (int i = 0; i < d.num_sdfs; i++) pack_frame(hinverse(to_h(d.sdfs[i].frame), false), &sdf_inv[3 * (size_t)i]);
@@ -394,6 +409,8 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   UP(upload(s, leafs, &D.leaf_prims));
   UP(upload(s, scene_wnodes, &D.scene_wnodes));
   UP(upload(s, shape_wnodes, &D.shape_wnodes));
+  UP(upload(s, enter, &D.scene_enter));
+  UP(upload(s, slot_of, &D.slot_of_instance));
   UP(upload(s, instances, &D.instances));
   UP(upload(s, shapes, &D.shapes));
   UP(upload(s, elems, &D.elems));

@@ -57,6 +57,12 @@ struct DScene {
   //   q3 = {ref0, ref1, axis, -} (ints); ref >= 0: internal wide node; ref < 0: leaf, ~ref = start<<4 | num
   const float4* scene_wnodes;
   const float4* shape_wnodes;
+  // "enter records": everything the traversal needs to enter the instance stored at a scene-BVH
+  // primitive slot, in one 96-byte gather instead of the prims[] -> instances[] -> shapes[] chain:
+  //   e0..e2 = inverse frame (packed), e3 = {root lo.xyz, root hi.x}, e4 = {root hi.y, root hi.z,
+  //   root_ref, wnode_offset}, e5 = {leaf_offset, instance id, translation_only, num_nodes} (ints)
+  const float4* scene_enter;      // 6 per scene-BVH primitive slot
+  const int*    slot_of_instance; // instance id -> slot (single-instance queries)
   int   scene_root_ref, pad1;
   float scene_root_lo_x, scene_root_lo_y, scene_root_lo_z, scene_root_hi_x, scene_root_hi_y, scene_root_hi_z;
   // geometry

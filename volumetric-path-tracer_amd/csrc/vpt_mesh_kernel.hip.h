@@ -114,32 +114,36 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
     return VPT_NONE;
   };
   // enter pending instances (pend = start<<4 | count) until one passes its root test; else pop
+  // enter one instance from its 96-byte enter record (vpt_device.h); false if its root box is missed
+  auto try_enter = [&](int slot) {
+    const float4* e = sc.scene_enter + 6 * (long long)slot;
+    float4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5];
+    f3   lo, ld, linv;
+    bool lslow;
+    if (__float_as_int(e5.z) && !wslow) {
+      // inverse frame = {I, -o}: 1*d + 0*d' + 0*d'' == d bit for bit when no component is zero, and
+      // ((1*o.x + 0*o.y) + 0*o.z) + t == o.x + t: skip the 3x3 product and the three divisions
+      lo = mk3(wo.x + e2.y, wo.y + e2.z, wo.z + e2.w), ld = wd, linv = winv, lslow = false;
+    } else {
+      frame inv = unpack_frame(e0, e1, e2);
+      lo = transform_point(inv, wo), ld = transform_vector(inv, wd);
+      linv = mk3(1 / ld.x, 1 / ld.y, 1 / ld.z), lslow = has_zero(ld);
+    }
+    float t0;
+    if (!(__float_as_int(e5.w) && box_test(lslow, mk3(e3.x, e3.y, e3.z), mk3(e3.w, e4.x, e4.y), lo, linv, tmin, tmax, t0))) return false;
+    co = lo, cd = ld, cinv = linv, csgn = sign_bits(linv), slow = lslow;
+    cur_inst = __float_as_int(e5.y), shape_base = sp;
+    wn    = sc.shape_wnodes + 4 * (long long)__float_as_int(e4.w);
+    leafs = sc.leaf_prims + 4 * (long long)__float_as_int(e5.x);
+    cur   = __float_as_int(e4.z);   // the instance's root: visited next with the same tmax
+    return true;
+  };
+  // enter pending instances (pend = start<<4 | count) until one passes its root test; else pop
   auto enter_next = [&]() {
     while (pend & 15) {
-      int id = sc.scene_prims[pend >> 4];
+      int slot = pend >> 4;
       pend += 15;
-      const DInstance& inst = sc.instances[id];
-      f3   lo, ld, linv;
-      bool lslow;
-      if (inst.translation_only && !wslow) {
-        // inverse frame = {I, -o}: 1*d + 0*d' + 0*d'' == d bit for bit when no component is zero, and
-        // ((1*o.x + 0*o.y) + 0*o.z) + t == o.x + t: skip the 3x3 product and the three divisions
-        float4 c = inst.inv[2];   // {z.z, o.x, o.y, o.z}
-        lo = mk3(wo.x + c.y, wo.y + c.z, wo.z + c.w), ld = wd, linv = winv, lslow = false;
-      } else {
-        frame inv = unpack_frame(inst.inv[0], inst.inv[1], inst.inv[2]);
-        lo = transform_point(inv, wo), ld = transform_vector(inv, wd);
-        linv = mk3(1 / ld.x, 1 / ld.y, 1 / ld.z), lslow = has_zero(ld);
-      }
-      const DShape& sh = sc.shapes[inst.shape];
-      float t0;
-      if (sh.num_nodes && box_test(lslow, ld3(sh.root_box), ld3(sh.root_box + 3), lo, linv, tmin, tmax, t0)) {
-        co = lo, cd = ld, cinv = linv, csgn = sign_bits(linv), slow = lslow;
-        cur_inst = id, shape_base = sp;
-        wn    = sc.shape_wnodes + 4 * (long long)sh.wnode_offset;
-        leafs = sc.leaf_prims + 4 * (long long)sh.leaf_offset;
-        return sh.root_ref;
-      }
+      if (try_enter(slot)) return cur;
     }
     return pop_valid();
   };
@@ -149,17 +153,9 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
     if (sc.num_scene_nodes && box_test(slow, mk3(sc.scene_root_lo_x, sc.scene_root_lo_y, sc.scene_root_lo_z),
                                   mk3(sc.scene_root_hi_x, sc.scene_root_hi_y, sc.scene_root_hi_z), co, cinv, tmin, tmax, t0))
       cur = sc.scene_root_ref;
-  } else {   // single-instance query: a one-entry "scene leaf"
-    const DInstance& inst = sc.instances[only_instance];
-    frame inv = unpack_frame(inst.inv[0], inst.inv[1], inst.inv[2]);
-    co = transform_point(inv, wo), cd = transform_vector(inv, wd);
-    cinv = mk3(1 / cd.x, 1 / cd.y, 1 / cd.z), csgn = sign_bits(cinv), slow = has_zero(cd);
-    const DShape& sh = sc.shapes[inst.shape];
-    cur_inst = only_instance, shape_base = 0;
-    wn    = sc.shape_wnodes + 4 * (long long)sh.wnode_offset;
-    leafs = sc.leaf_prims + 4 * (long long)sh.leaf_offset;
-    float t0;
-    if (sh.num_nodes && box_test(slow, ld3(sh.root_box), ld3(sh.root_box + 3), co, cinv, tmin, tmax, t0)) cur = sh.root_ref;
+  } else {   // single-instance query (yocto_bvh.cpp:874-881)
+    if (!try_enter(sc.slot_of_instance[only_instance])) cur = VPT_NONE;
+    shape_base = 0;
   }
 
   while (true) {

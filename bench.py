@@ -129,6 +129,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    scene_name = os.path.basename(os.path.dirname(os.path.abspath(args.scene)))
+    data_desc = ("reference scene tests/03_volume (real assets), deterministic PCG32 seeds" if args.scene == SCENE else
+                 f"{scene_name}: substitute assets (tests/golden/make_scenes.py), deterministic PCG32 seeds")
     samples_per_step = width * height * args.spp
     value = samples_per_step * args.steps / elapsed * 1e-6
 
@@ -153,7 +156,7 @@ def main():
             traffic = round(json.load(open(tfile))["bytes_per_sample"] * per_launch_samples)
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "kernel": "vpt_mesh_kernel<%s>" % args.shader, "kernel_ms": round(mean_ms, 3),
+                    "kernel": ("vpt_render_kernel<%s>" if args.shader.startswith("implicit") else "vpt_mesh_kernel<%s>") % args.shader, "kernel_ms": round(mean_ms, 3),
                     "algorithmic_bytes_per_sample": round(bps, 1)}
         if world == 1 and args.cpu_sample != "0":
             sres, sspp = (int(x) for x in args.cpu_sample.split("x"))
@@ -171,7 +174,7 @@ def main():
                 cpu_baseline = {"value": round(info["msamples_per_s"], 4), "unit": "Msamples/s", "cores": min(ncores, info["threads"]),
                                 "threads_started": info["threads"],
                                 "kind": "reference",
-                                "sample": f"03_volume {info['width']}x{info['height']}x{sspp}spp, reference renderer (g++ -O2)"}
+                                "sample": f"{scene_name} {info['width']}x{info['height']}x{sspp}spp, reference renderer (g++ -O2)"}
             else:
                 sp = vpt.PathtraceParams(resolution=sres, samples=1 << 30, shader=args.shader, bounces=args.bounces)
                 sstate = scene.make_state(sp)
@@ -180,13 +183,13 @@ def main():
                 dt = time.perf_counter() - t1
                 cpu_baseline = {"value": round(sstate.width * sstate.height * sspp / dt * 1e-6, 4), "unit": "Msamples/s",
                                 "cores": ncores, "kind": "port",
-                                "sample": f"03_volume {sstate.width}x{sstate.height}x{sspp}spp, oracle/vpt_oracle.cpp"}
+                                "sample": f"{scene_name} {sstate.width}x{sstate.height}x{sspp}spp, oracle/vpt_oracle.cpp"}
         line = {
             "metric": "Msamples/sec", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "reference scene tests/03_volume (real assets), deterministic PCG32 seeds",
-            "config": {"workload": f"03_volume {args.shader} bounces={args.bounces} {width}x{height}x{args.spp}spp per step",
+            "dtype": "f32", "data": data_desc,
+            "config": {"workload": f"{scene_name} {args.shader} bounces={args.bounces} {width}x{height}x{args.spp}spp per step",
                        "tile": f"{args.tile}x{args.tile}", "parallelism": f"tiles%{world}" if world > 1 else "1gpu",
                        "samples_per_step": samples_per_step},
             "roofline": roofline, "cpu_baseline": cpu_baseline,

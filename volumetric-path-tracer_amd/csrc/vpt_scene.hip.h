@@ -165,13 +165,18 @@ VPT_DEV f4 lookup_texture(const DScene& sc, const vpt_texture& t, int i, int j, 
   if (as_linear && !t.linear) return mk4(sc.srgb_lut[b.x], sc.srgb_lut[b.y], sc.srgb_lut[b.z], b.w / 255.0f);
   return mk4(b.x / 255.0f, b.y / 255.0f, b.z / 255.0f, b.w / 255.0f);
 }
+// fmod(x, 1.0f) (yocto_scene.cpp:141-144) without ocml's generic remainder loop: for finite x the
+// fractional part x - trunc(x) is exact in float32 and fmod's result carries the sign of x (also for a
+// zero result), hence the copysign; inf / NaN give NaN in both forms.
+VPT_DEV float fmod1(float x) { return copysignf(x - truncf(x), x); }
+
 VPT_DEV f4 eval_texture(const DScene& sc, int texture, f2 uv, bool as_linear) {
   if (texture == VPT_INVALID) return mk4(1, 1, 1, 1);
   const vpt_texture& t = sc.textures[texture];
   if (t.width == 0 || t.height == 0) return mk4(0, 0, 0, 0);
-  float s = fmodf(uv.x, 1.0f) * t.width;
+  float s = fmod1(uv.x) * t.width;
   if (s < 0) s += t.width;
-  float tt = fmodf(uv.y, 1.0f) * t.height;
+  float tt = fmod1(uv.y) * t.height;
   if (tt < 0) tt += t.height;
   int   i = clampi((int)s, 0, t.width - 1), j = clampi((int)tt, 0, t.height - 1);
   int   ii = (i + 1) % t.width, jj = (j + 1) % t.height;

@@ -57,30 +57,68 @@ void pack_frame(const hframe& f, float4* out) {
   out[2] = make_float4(f.z.z, f.o.x, f.o.y, f.o.z);
 }
 
-// Wide nodes (vpt_device.h): one 64-byte record per internal node with both child boxes + refs.
-// Returns the reference of the root and its box; appends to `out`; refs are relative to this BVH.
-int build_wide_nodes(const vpt_bvh_node* nodes, int count, std::vector<float4>& out, float root_box[6]) {
+// Quad nodes (vpt_device.h): one 128-byte record per internal node at even depth, holding the boxes and
+// references of its (up to) four grandchildren in the binary BVH: slots 0,1 = children of child 0 (or
+// child 0 itself when it is a leaf, slot 1 empty), slots 2,3 likewise for child 1.  Layout: lo.x[4],
+// lo.y[4], lo.z[4], hi.x[4], hi.y[4], hi.z[4], ref[4], {axis | axis0 << 2 | axis1 << 4, 0, 0, 0}.
+// ref >= 0: quad node (relative to this BVH), ~ref = start << 4 | count: leaf, VPT_NONE_REF: empty slot.
+// Returns the reference of the root and its box, appends to `out`; *need = worst-case number of stack
+// entries a traversal of this BVH holds at once (three pending siblings per quad level).
+constexpr int VPT_NONE_REF = -2147483647 - 1;
+int build_quad_nodes(const vpt_bvh_node* nodes, int count, std::vector<float4>& out, float root_box[6], int* need) {
   for (int k = 0; k < 6; k++) root_box[k] = 0;
+  *need = 0;
   if (count <= 0) return ~0;   // empty leaf
-  std::vector<int> wide_index((size_t)count, -1);
-  int nwide = 0;
-  for (int i = 0; i < count; i++)
-    if (nodes[i].internal) wide_index[(size_t)i] = nwide++;
-  auto ref_of = [&](int i) { return nodes[i].internal ? wide_index[(size_t)i] : ~((nodes[i].start << 4) | (nodes[i].num & 15)); };
-  size_t base = out.size();
-  out.resize(base + 4 * (size_t)nwide);
-  for (int i = 0; i < count; i++) {
-    if (!nodes[i].internal) continue;
-    const vpt_bvh_node &a = nodes[nodes[i].start], &b = nodes[nodes[i].start + 1];
-    float4* q = &out[base + 4 * (size_t)wide_index[(size_t)i]];
-    q[0] = make_float4(a.bbox_min[0], a.bbox_min[1], a.bbox_min[2], a.bbox_max[0]);
-    q[1] = make_float4(a.bbox_max[1], a.bbox_max[2], b.bbox_min[0], b.bbox_min[1]);
-    q[2] = make_float4(b.bbox_min[2], b.bbox_max[0], b.bbox_max[1], b.bbox_max[2]);
-    int meta[4] = {ref_of(nodes[i].start), ref_of(nodes[i].start + 1), nodes[i].axis, 0};
-    memcpy(&q[3], meta, 16);
-  }
   for (int k = 0; k < 3; k++) root_box[k] = nodes[0].bbox_min[k], root_box[3 + k] = nodes[0].bbox_max[k];
-  return ref_of(0);
+  auto leaf_code = [&](int i) { return ~((nodes[i].start << 4) | (nodes[i].num & 15)); };
+  if (!nodes[0].internal) return leaf_code(0);
+  // binary nodes that become quad nodes, in depth-first preorder (a node's subtree stays close to it)
+  std::vector<int> quad_of((size_t)count, -1), order, todo{0};
+  auto slots_of = [&](int i, int slot[4], int axes[3]) {
+    axes[0] = nodes[i].axis, axes[1] = axes[2] = 0;
+    for (int side = 0; side < 2; side++) {
+      int c = nodes[i].start + side;
+      if (nodes[c].internal) slot[2 * side] = nodes[c].start, slot[2 * side + 1] = nodes[c].start + 1, axes[1 + side] = nodes[c].axis;
+      else slot[2 * side] = c, slot[2 * side + 1] = -1;
+    }
+  };
+  while (!todo.empty()) {
+    int i = todo.back();
+    todo.pop_back();
+    quad_of[(size_t)i] = (int)order.size();
+    order.push_back(i);
+    int slot[4], axes[3];
+    slots_of(i, slot, axes);
+    for (int k = 3; k >= 0; k--)
+      if (slot[k] >= 0 && nodes[slot[k]].internal) todo.push_back(slot[k]);
+  }
+  size_t base = out.size();
+  out.resize(base + 8 * order.size());
+  std::vector<int> node_need(order.size(), 0);
+  for (size_t n = order.size(); n-- > 0;) {   // children come after their parent in preorder: fill bottom-up
+    int i = order[n], slot[4], axes[3];
+    slots_of(i, slot, axes);
+    float box[6][4];
+    int   ref[4], present = 0, deepest = 0;
+    for (int k = 0; k < 4; k++) {
+      for (int c = 0; c < 6; c++) box[c][k] = 0;
+      ref[k] = VPT_NONE_REF;
+      if (slot[k] < 0) continue;
+      const vpt_bvh_node& ch = nodes[slot[k]];
+      for (int c = 0; c < 3; c++) box[c][k] = ch.bbox_min[c], box[3 + c][k] = ch.bbox_max[c];
+      ref[k] = ch.internal ? quad_of[(size_t)slot[k]] : leaf_code(slot[k]);
+      present++;
+      if (ch.internal && node_need[(size_t)quad_of[(size_t)slot[k]]] > deepest) deepest = node_need[(size_t)quad_of[(size_t)slot[k]]];
+    }
+    node_need[n] = present - 1 + deepest;
+    float4* q = &out[base + 8 * n];
+    for (int c = 0; c < 6; c++) q[c] = make_float4(box[c][0], box[c][1], box[c][2], box[c][3]);
+    memcpy(&q[6], ref, 16);
+    int meta[4] = {axes[0] | (axes[1] << 2) | (axes[2] << 4), 0, 0, 0};
+    memcpy(&q[7], meta, 16);
+  }
+  *need = node_need[0];
+  return 0;
 }
 
 int bvh_depth(const vpt_bvh_node* nodes, int count, int root, int depth, int limit) {
@@ -97,7 +135,10 @@ struct vpt_scene {
   int                device = 0;
   DScene             d      = {};
   std::vector<void*> allocs;
-  int                stack_cap = 16;
+  int                stack_cap = 16;    // binary-BVH kernels (implicit shaders, stream k_shade): refs only
+  int                stack_lds4 = 8, stack_spill4 = 0;   // quad-node traversal: (ref, t0) entries in LDS / in HBM
+  void*              spill = nullptr;
+  long long          spill_lanes = 0;
   // staging for the host-state entry point vpt_render()
   void *s_image = nullptr, *s_hits = nullptr, *s_rng = nullptr;   // tile-major state
   void *r_image = nullptr, *r_hits = nullptr, *r_rng = nullptr;   // row-major mirror
@@ -278,6 +319,7 @@ void vpt_scene_destroy(vpt_scene* s) {
   for (void* p : {s->s_image, s->s_hits, s->s_rng, s->r_image, s->r_hits, s->r_rng})
     if (p) (void)hipFree(p);
   for (void* p : s->path_allocs) (void)hipFree(p);
+  if (s->spill) (void)hipFree(s->spill);
   if (s->host_counts) (void)hipHostFree(s->host_counts);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -313,7 +355,7 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   std::vector<DShape> shapes((size_t)d.num_shapes);
   std::vector<int4>   elems;
   std::vector<float4> leafs, shape_wnodes, scene_wnodes;
-  int max_shape_depth = 0;
+  int max_shape_depth = 0, max_shape_need4 = 0;
   for (int i = 0; i < d.num_shapes; i++) {
     const vpt_shape& sh = d.shapes[i];
     DShape& o = shapes[i];
@@ -345,23 +387,32 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
         leafs.push_back(p);
       }
     }
-    o.wnode_offset = (int)(shape_wnodes.size() / 4);
-    o.root_ref     = build_wide_nodes(d.shape_bvh_nodes + sh.bvh_node_offset, sh.num_bvh_nodes, shape_wnodes, o.root_box);
+    o.wnode_offset = (int)(shape_wnodes.size() / 8);
+    int need4 = 0;
+    o.root_ref     = build_quad_nodes(d.shape_bvh_nodes + sh.bvh_node_offset, sh.num_bvh_nodes, shape_wnodes, o.root_box, &need4);
     int depth = o.num_nodes ? bvh_depth(d.shape_bvh_nodes + sh.bvh_node_offset, sh.num_bvh_nodes, 0, 0, 4096) : 0;
     o.stack_need = depth + 2;
     if (depth > max_shape_depth) max_shape_depth = depth;
+    if (need4 > max_shape_need4) max_shape_need4 = need4;
   }
   int scene_depth = d.num_scene_bvh_nodes ? bvh_depth(d.scene_bvh_nodes, d.num_scene_bvh_nodes, 0, 0, 4096) : 0;
   float scene_box[6];
-  D.scene_root_ref = build_wide_nodes(d.scene_bvh_nodes, d.num_scene_bvh_nodes, scene_wnodes, scene_box);
+  int scene_need4 = 0;
+  D.scene_root_ref = build_quad_nodes(d.scene_bvh_nodes, d.num_scene_bvh_nodes, scene_wnodes, scene_box, &scene_need4);
   D.scene_root_lo_x = scene_box[0], D.scene_root_lo_y = scene_box[1], D.scene_root_lo_z = scene_box[2];
   D.scene_root_hi_x = scene_box[3], D.scene_root_hi_y = scene_box[4], D.scene_root_hi_z = scene_box[5];
   // stack entries alive at once: one pending sibling per level (+ the two just pushed), scene level
   // entries stay below the entries of the instance being traversed
   int need = (scene_depth + 2) + (max_shape_depth + 2);
   s->stack_cap = ((need > 8 ? need : 8) + 3) & ~3;
-  if ((size_t)s->stack_cap * 2 * VPT_BLOCK * sizeof(int) > 64 * 1024)
-    return fail(VPT_ERR_UNSUPPORTED, "BVH depth %d needs a %d-entry traversal stack; the LDS stack holds 32", need, s->stack_cap);
+  if ((size_t)s->stack_cap * VPT_BLOCK * sizeof(int) > 64 * 1024)
+    return fail(VPT_ERR_UNSUPPORTED, "BVH depth %d needs a %d-entry traversal stack; the LDS stack holds 64", need, s->stack_cap);
+  // quad-node traversal: worst case = three pending siblings per quad level of the scene BVH plus of the
+  // deepest shape BVH.  24 entries per lane keep three 256-lane workgroups on a CU (3 x 48 KB of 160 KB);
+  // whatever the worst case needs beyond that lives in HBM (lane_stack2).
+  int need4 = scene_need4 + max_shape_need4 + 1;
+  s->stack_lds4   = need4 < 8 ? 8 : need4 > 24 ? 24 : ((need4 + 3) & ~3);
+  s->stack_spill4 = need4 > s->stack_lds4 ? need4 - s->stack_lds4 : 0;
 
   for (int i = 0; i < d.num_lights; i++)
     if (d.lights[i].instance >= 0 && shapes[(size_t)d.instances[d.lights[i].instance].shape].root_ref >= 0) s->large_mesh_lights = true;
@@ -437,7 +488,7 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
-    size_t lds_block = (size_t)s->stack_cap * 2 * VPT_BLOCK * sizeof(int);
+    size_t lds_block = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int);
     int per_cu = (int)((160 * 1024) / (lds_block ? lds_block : 1));
     if (per_cu > 4) per_cu = 4;   // __launch_bounds__(256, 4): 4 waves/SIMD = 4 workgroups/CU
     if (per_cu < 1) per_cu = 1;
@@ -537,13 +588,27 @@ static int ensure_paths(vpt_scene* s, long long nslots) {
   return VPT_OK;
 }
 
+// HBM part of the traversal stacks for a launch of `lanes` lanes (only scenes whose worst case exceeds the LDS part)
+static int stack_config(vpt_scene* s, long long lanes, stack_cfg& cfg) {
+  if (s->stack_spill4 > 0 && lanes > s->spill_lanes) {
+    if (s->spill) (void)hipFree(s->spill);
+    s->spill = nullptr, s->spill_lanes = 0;
+    HIP_TRY(hipMalloc(&s->spill, (size_t)lanes * (size_t)s->stack_spill4 * sizeof(int2)));
+    s->spill_lanes = lanes;
+  }
+  cfg.cap = s->stack_lds4, cfg.spill = s->stack_spill4, cfg.mem = (int2*)s->spill, cfg.lanes = lanes;
+  return VPT_OK;
+}
+
 // The streaming form of K1: k_begin, then (k_trace, k_shade) pairs until every queue is empty.
 // Queue sizes only shrink, so the grid follows the last count read back (every 16 iterations).
 template <int K>
 static int render_stream(vpt_scene* s, const DParams& pr, float4* img, int* hit, ulonglong2* rng, hipStream_t st) {
   if (int rc = ensure_paths(s, pr.nslots)) return rc;
   const DPaths& P = s->paths;
-  size_t lds_trace = (size_t)s->stack_cap * 2 * VPT_BLOCK * sizeof(int);
+  size_t lds_trace = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int);
+  stack_cfg stack;
+  if (int rc = stack_config(s, ((long long)pr.nslots + VPT_BLOCK - 1) / VPT_BLOCK * VPT_BLOCK, stack)) return rc;
   size_t lds_shade = s->large_mesh_lights ? (size_t)s->stack_cap * VPT_BLOCK * sizeof(int) : 0;
   HIP_TRY(hipMemsetAsync(P.count, 0, 16, st));
   int blocks = (pr.nslots + VPT_BLOCK - 1) / VPT_BLOCK;
@@ -553,7 +618,7 @@ static int render_stream(vpt_scene* s, const DParams& pr, float4* img, int* hit,
   long long upper = pr.nslots, it = 0;
   while (upper > 0) {
     int grid = (int)((upper + VPT_BLOCK - 1) / VPT_BLOCK);
-    hipLaunchKernelGGL(vpt_stream_trace, dim3(grid), dim3(VPT_BLOCK), lds_trace, st, s->d, P, q, s->stack_cap);
+    hipLaunchKernelGGL(vpt_stream_trace, dim3(grid), dim3(VPT_BLOCK), lds_trace, st, s->d, P, q, stack);
     hipLaunchKernelGGL(vpt_stream_shade<K>, dim3(grid), dim3(VPT_BLOCK), lds_shade, st, s->d, pr, P, q, img, hit, rng, s->stack_cap);
     q ^= 1;
     if ((++it & 15) == 0) {
@@ -591,7 +656,9 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
   hipStream_t st = (hipStream_t)stream;
   dim3   grid((pr.nslots + VPT_BLOCK - 1) / VPT_BLOCK), block(VPT_BLOCK);
   size_t lds  = (size_t)s->stack_cap * VPT_BLOCK * sizeof(int);       // implicit kernels: refs only
-  size_t lds2 = (size_t)s->stack_cap * 2 * VPT_BLOCK * sizeof(int);   // mesh kernel: (ref, t0) pairs
+  size_t lds2 = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int);   // mesh kernel: (ref, t0) pairs
+  stack_cfg stack;
+  if (int rc = stack_config(s, (long long)grid.x * VPT_BLOCK, stack)) return rc;
   auto   img = (float4*)d_image;
   auto   hit = (int*)d_hits;
   auto   rng = (ulonglong2*)d_rng;
@@ -602,7 +669,7 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
     if (use_stream_pipeline()) {                                                                                \
       if (int rc_ = render_stream<K>(s, pr, img, hit, rng, st)) return rc_;                                     \
     } else {                                                                                                    \
-      hipLaunchKernelGGL(vpt_mesh_kernel<K>, grid, block, lds2, st, s->d, pr, img, hit, rng, s->stack_cap);    \
+      hipLaunchKernelGGL(vpt_mesh_kernel<K>, grid, block, lds2, st, s->d, pr, img, hit, rng, stack);           \
     }                                                                                                           \
   } while (0)
   switch (params->shader) {

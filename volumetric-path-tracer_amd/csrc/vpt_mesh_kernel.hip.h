@@ -31,19 +31,40 @@
 #pragma once
 #include "vpt_kernels.hip.h"
 
+// (ref, t0) stack of one lane: the first `cap` entries live in LDS (entry-major: conflict-free), deeper
+// ones in a per-launch HBM array (entry-major too: coalesced).  `cap` covers what traversals use in
+// practice; the HBM part only makes the worst case (three pending siblings on every quad level) safe.
+struct stack_cfg {
+  int        cap;      // entries per lane in LDS
+  int        spill;    // entries per lane in HBM
+  int2*      mem;      // spill * lanes entries
+  long long  lanes;    // lanes of the launch (= entry stride)
+};
 struct lane_stack2 {
-  int* base;   // &lds[threadIdx.x]; entry e: ref at base[(2e)*VPT_BLOCK], t0 at base[(2e+1)*VPT_BLOCK]
-  int  cap;
+  int*      base;   // &lds[threadIdx.x]; entry e: ref at base[(2e)*VPT_BLOCK], t0 at base[(2e+1)*VPT_BLOCK]
+  int       cap;
+  int2*     deep;   // &mem[global lane]; entry cap + e at deep[e * lanes]
+  long long lanes;
   VPT_DEV void push(int& sp, int ref, float t0) const {
     if (sp < cap) base[(2 * sp) * VPT_BLOCK] = ref, base[(2 * sp + 1) * VPT_BLOCK] = __float_as_int(t0);
+    else deep[(sp - cap) * lanes] = make_int2(ref, __float_as_int(t0));
     sp++;
   }
   VPT_DEV void pop(int& sp, int& ref, float& t0) const {
     sp--;
-    int s = sp < cap ? sp : cap - 1;
-    ref = base[(2 * s) * VPT_BLOCK], t0 = __int_as_float(base[(2 * s + 1) * VPT_BLOCK]);
+    if (sp < cap) ref = base[(2 * sp) * VPT_BLOCK], t0 = __int_as_float(base[(2 * sp + 1) * VPT_BLOCK]);
+    else {
+      int2 e = deep[(sp - cap) * lanes];
+      ref = e.x, t0 = __int_as_float(e.y);
+    }
   }
 };
+VPT_DEV lane_stack2 make_lane_stack(int* lds, const stack_cfg& cfg) {
+  lane_stack2 stk;
+  stk.base = lds + threadIdx.x, stk.cap = cfg.cap;
+  stk.deep = cfg.mem + ((long long)blockIdx.x * VPT_BLOCK + threadIdx.x), stk.lanes = cfg.lanes;
+  return stk;
+}
 
 #define VPT_BOX_K 1.00000024f
 
@@ -58,13 +79,17 @@ VPT_DEV bool box_pass(f3 bmin, f3 bmax, f3 o, f3 dinv, float tmin, float tmax, f
 }
 VPT_DEV int sign_bits(f3 dinv) { return (dinv.x < 0 ? 1 : 0) | (dinv.y < 0 ? 2 : 0) | (dinv.z < 0 ? 4 : 0); }
 
-// same test with 3-operand min/max; only valid when no product can be NaN (no zero in the direction)
+// Hardware min/max (no sNaN quieting moves around them: the operands below are never NaN)
+VPT_DEV float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+VPT_DEV float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+VPT_DEV float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+VPT_DEV float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// same test with 3-operand min/max; only valid when no product can be NaN (no zero in the direction):
+// min/max of non-NaN values do not depend on how they are associated, so the result is the reference's
 VPT_DEV bool box_pass_fast(f3 bmin, f3 bmax, f3 o, f3 dinv, float tmin, float tmax, float& t0) {
-  f3    a  = (bmin - o) * dinv, b = (bmax - o) * dinv;
-  float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, b.x), __builtin_fminf(a.y, b.y)), __builtin_fminf(a.z, b.z));
-  float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, b.x), __builtin_fmaxf(a.y, b.y)), __builtin_fmaxf(a.z, b.z));
-  t0       = __builtin_fmaxf(lo, tmin);
-  float t1 = __builtin_fminf(hi, tmax) * VPT_BOX_K;
+  f3 a = (bmin - o) * dinv, b = (bmax - o) * dinv;
+  t0       = hw_max3(hw_max(hw_min(a.x, b.x), hw_min(a.y, b.y)), hw_min(a.z, b.z), tmin);
+  float t1 = hw_min3(hw_min(hw_max(a.x, b.x), hw_max(a.y, b.y)), hw_max(a.z, b.z), tmax) * VPT_BOX_K;
   return t0 <= t1;
 }
 VPT_DEV bool box_test(bool slow, f3 bmin, f3 bmax, f3 o, f3 dinv, float tmin, float tmax, float& t0) {
@@ -133,7 +158,7 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
     if (!(__float_as_int(e5.w) && box_test(lslow, mk3(e3.x, e3.y, e3.z), mk3(e3.w, e4.x, e4.y), lo, linv, tmin, tmax, t0))) return false;
     co = lo, cd = ld, cinv = linv, csgn = sign_bits(linv), slow = lslow;
     cur_inst = __float_as_int(e5.y), shape_base = sp;
-    wn    = sc.shape_wnodes + 4 * (long long)__float_as_int(e4.w);
+    wn    = sc.shape_wnodes + 8 * (long long)__float_as_int(e4.w);
     leafs = sc.leaf_prims + 4 * (long long)__float_as_int(e5.x);
     cur   = __float_as_int(e4.z);   // the instance's root: visited next with the same tmax
     return true;
@@ -159,26 +184,51 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
   }
 
   while (true) {
-    // ---- phase A: internal nodes ---------------------------------------------------------------------
+    // ---- phase A: internal (quad) nodes ----------------------------------------------------------------
     while (cur >= 0) {
-      const float4* q = wn + 4 * (long long)cur;
-      float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-      float  ta, tb;
-      bool   pa = box_test(slow, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), co, cinv, tmin, tmax, ta);
-      bool   pb = box_test(slow, mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), co, cinv, tmin, tmax, tb);
-      int    ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y), axis = __float_as_int(q3.z);
-      bool   one_first = (csgn >> axis) & 1;   // the reference pushes 0 then 1 => child 1 is visited first
-      int    first = one_first ? ref1 : ref0, second = one_first ? ref0 : ref1;
-      bool   pf = one_first ? pb : pa, ps = one_first ? pa : pb;
-      float  ts = one_first ? ta : tb;
-      if (pf) {
-        if (ps) stk.push(sp, second, ts);
-        cur = first;
-      } else if (ps) {
-        cur = second;
+      const float4* q = wn + 8 * (long long)cur;
+      float4 lx = q[0], ly = q[1], lz = q[2], hx = q[3], hy = q[4], hz = q[5], qr = q[6];
+      int    meta = __float_as_int(q[7].x);
+      float  t0, t1, t2, t3;
+      bool   p0, p1, p2, p3;
+      if (__builtin_amdgcn_ballot_w64(slow) != 0) {   // some lane may meet 0 * inf: the reference's NaN-asymmetric form for all
+        p0 = box_pass(mk3(lx.x, ly.x, lz.x), mk3(hx.x, hy.x, hz.x), co, cinv, tmin, tmax, t0);
+        p1 = box_pass(mk3(lx.y, ly.y, lz.y), mk3(hx.y, hy.y, hz.y), co, cinv, tmin, tmax, t1);
+        p2 = box_pass(mk3(lx.z, ly.z, lz.z), mk3(hx.z, hy.z, hz.z), co, cinv, tmin, tmax, t2);
+        p3 = box_pass(mk3(lx.w, ly.w, lz.w), mk3(hx.w, hy.w, hz.w), co, cinv, tmin, tmax, t3);
       } else {
-        cur = pop_valid();
+        p0 = box_pass_fast(mk3(lx.x, ly.x, lz.x), mk3(hx.x, hy.x, hz.x), co, cinv, tmin, tmax, t0);
+        p1 = box_pass_fast(mk3(lx.y, ly.y, lz.y), mk3(hx.y, hy.y, hz.y), co, cinv, tmin, tmax, t1);
+        p2 = box_pass_fast(mk3(lx.z, ly.z, lz.z), mk3(hx.z, hy.z, hz.z), co, cinv, tmin, tmax, t2);
+        p3 = box_pass_fast(mk3(lx.w, ly.w, lz.w), mk3(hx.w, hy.w, hz.w), co, cinv, tmin, tmax, t3);
       }
+      // slots 0,1 = children of child 0, slots 2,3 = children of child 1 of the binary node.  The reference
+      // pushes child 0 then child 1 when the ray is negative along the node's axis (child 1 popped first),
+      // and does the same one level down when that child is popped: visit order = [group][member].
+      int  r0 = p0 ? __float_as_int(qr.x) : VPT_NONE, r1 = p1 ? __float_as_int(qr.y) : VPT_NONE;
+      int  r2 = p2 ? __float_as_int(qr.z) : VPT_NONE, r3 = p3 ? __float_as_int(qr.w) : VPT_NONE;
+      bool gn = (csgn >> (meta & 3)) & 1, g0 = (csgn >> ((meta >> 2) & 3)) & 1, g1 = (csgn >> ((meta >> 4) & 3)) & 1;
+      int   a0 = g0 ? r1 : r0, a1 = g0 ? r0 : r1, b0 = g1 ? r3 : r2, b1 = g1 ? r2 : r3;
+      float s0 = g0 ? t1 : t0, s1 = g0 ? t0 : t1, u0 = g1 ? t3 : t2, u1 = g1 ? t2 : t3;
+      int   v0 = gn ? b0 : a0, v1 = gn ? b1 : a1, v2 = gn ? a0 : b0, v3 = gn ? a1 : b1;
+      float w0 = gn ? u0 : s0, w1 = gn ? u1 : s1, w2 = gn ? s0 : u0, w3 = gn ? s1 : u1;
+      // push the later-visited ones (last first); the first-visited one is taken directly: it would be
+      // popped next with the same tmax, so its pop test is a tautology
+      int   next = v3;
+      float nt   = w3;
+      if (v2 != VPT_NONE) {
+        if (next != VPT_NONE) stk.push(sp, next, nt);
+        next = v2, nt = w2;
+      }
+      if (v1 != VPT_NONE) {
+        if (next != VPT_NONE) stk.push(sp, next, nt);
+        next = v1, nt = w1;
+      }
+      if (v0 != VPT_NONE) {
+        if (next != VPT_NONE) stk.push(sp, next, nt);
+        next = v0;
+      }
+      cur = next != VPT_NONE ? next : pop_valid();
     }
     if (cur == VPT_NONE) {
       if (shape_base < 0 || only_instance >= 0) break;   // nothing left: query finished
@@ -280,11 +330,9 @@ enum { ST_NEW = 0, ST_MAIN = 1, ST_LPDF = 2 };
 
 template <int SH>
 __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel(DScene sc, DParams pr,
-    float4* __restrict__ image, int* __restrict__ hits, ulonglong2* __restrict__ rngs, int stack_cap) {
+    float4* __restrict__ image, int* __restrict__ hits, ulonglong2* __restrict__ rngs, stack_cfg stack) {
   extern __shared__ int lds_stack[];
-  lane_stack2 stk;
-  stk.base = lds_stack + threadIdx.x;
-  stk.cap  = stack_cap;
+  const lane_stack2 stk = make_lane_stack(lds_stack, stack);
 
   int slot = blockIdx.x * VPT_BLOCK + threadIdx.x;
   int px = 0, py = 0;

@@ -1,0 +1,21 @@
+import os, sys, ctypes
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np, vpt_loader
+vpt = vpt_loader.load()
+lib = ctypes.CDLL(os.environ['VPT_HIP_LIB'])
+scene = vpt.HostScene('tests/golden/scenes/03_volume/volume.json')
+dev = vpt.DeviceScene(scene, 0)
+p = vpt.PathtraceParams(resolution=1280, samples=1 << 30, shader='volpathtrace', bounces=64)
+st = scene.make_state(p)
+spp = 16
+out = (ctypes.c_ulonglong * 64)()
+lib.vpt_debug_counts(out, 1)
+dev.pathtrace_samples(st, p, spp)
+lib.vpt_debug_counts(out, 0)
+names = ['node step', 'prim test', 'instance entry', 'outer iteration', 'trip (query)', 'pop', 'miss', 'surface', 'volume', 'lights', 'generate', 'leaf']
+nsamp = st.width * st.height * spp
+slots = nsamp / 64
+print(f"{'section':20s} {'wave-exec/sample-slot':>22s} {'lane-exec/sample':>18s} {'avg lanes':>10s}")
+for k, n in enumerate(names):
+    w, l = out[2 * k], out[2 * k + 1]
+    if w: print(f"{n:20s} {w / slots:22.2f} {l / nsamp:18.2f} {l / w:10.1f}")

@@ -413,6 +413,9 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   int need4 = scene_need4 + max_shape_need4 + 1;
   s->stack_lds4   = need4 < 8 ? 8 : need4 > 24 ? 24 : ((need4 + 3) & ~3);
   s->stack_spill4 = need4 > s->stack_lds4 ? need4 - s->stack_lds4 : 0;
+  if (getenv("VPT_DEBUG"))
+    fprintf(stderr, "[vpt] binary depth scene %d shape %d; quad stack need scene %d + shape %d + 1 -> %d in LDS + %d in HBM\n",
+        scene_depth, max_shape_depth, scene_need4, max_shape_need4, s->stack_lds4, s->stack_spill4);
 
   for (int i = 0; i < d.num_lights; i++)
     if (d.lights[i].instance >= 0 && shapes[(size_t)d.instances[d.lights[i].instance].shape].root_ref >= 0) s->large_mesh_lights = true;
@@ -618,7 +621,8 @@ static int render_stream(vpt_scene* s, const DParams& pr, float4* img, int* hit,
   long long upper = pr.nslots, it = 0;
   while (upper > 0) {
     int grid = (int)((upper + VPT_BLOCK - 1) / VPT_BLOCK);
-    hipLaunchKernelGGL(vpt_stream_trace, dim3(grid), dim3(VPT_BLOCK), lds_trace, st, s->d, P, q, stack);
+    if (stack.spill) hipLaunchKernelGGL(vpt_stream_trace<true>, dim3(grid), dim3(VPT_BLOCK), lds_trace, st, s->d, P, q, stack);
+    else hipLaunchKernelGGL(vpt_stream_trace<false>, dim3(grid), dim3(VPT_BLOCK), lds_trace, st, s->d, P, q, stack);
     hipLaunchKernelGGL(vpt_stream_shade<K>, dim3(grid), dim3(VPT_BLOCK), lds_shade, st, s->d, pr, P, q, img, hit, rng, s->stack_cap);
     q ^= 1;
     if ((++it & 15) == 0) {
@@ -668,8 +672,10 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
   do {                                                                                                          \
     if (use_stream_pipeline()) {                                                                                \
       if (int rc_ = render_stream<K>(s, pr, img, hit, rng, st)) return rc_;                                     \
+    } else if (stack.spill) {                                                                                   \
+      hipLaunchKernelGGL((vpt_mesh_kernel<K, true>), grid, block, lds2, st, s->d, pr, img, hit, rng, stack);    \
     } else {                                                                                                    \
-      hipLaunchKernelGGL(vpt_mesh_kernel<K>, grid, block, lds2, st, s->d, pr, img, hit, rng, stack);           \
+      hipLaunchKernelGGL((vpt_mesh_kernel<K, false>), grid, block, lds2, st, s->d, pr, img, hit, rng, stack);   \
     }                                                                                                           \
   } while (0)
   switch (params->shader) {
@@ -739,5 +745,17 @@ int vpt_render(vpt_scene* s, const vpt_params* params, int nsamples, int width, 
   *samples_io += todo;
   return VPT_OK;
 }
+
+#ifdef VPT_COUNTERS
+// diagnostic build only: read (and optionally clear) the section counters of vpt_mesh_kernel.hip.h
+int vpt_debug_counts(unsigned long long* out64, int reset) {
+  if (out64) HIP_TRY(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_vpt_cnt), sizeof(unsigned long long) * 64));
+  if (reset) {
+    unsigned long long zero[64] = {};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_vpt_cnt), zero, sizeof(zero)));
+  }
+  return VPT_OK;
+}
+#endif
 
 }  // extern "C"

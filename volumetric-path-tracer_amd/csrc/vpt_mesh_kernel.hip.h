@@ -31,6 +31,23 @@
 #pragma once
 #include "vpt_kernels.hip.h"
 
+// Diagnostic build (-DVPT_COUNTERS): how often a wave executes each code section and with how many
+// active lanes.  Slot 2k counts wave executions, slot 2k+1 the lanes active in them.  Never in the product build.
+#ifdef VPT_COUNTERS
+__device__ unsigned long long g_vpt_cnt[64];
+VPT_DEV void vpt_cnt(int k) {
+  unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+    atomicAdd(&g_vpt_cnt[2 * k], 1ull);
+    atomicAdd(&g_vpt_cnt[2 * k + 1], (unsigned long long)__popcll(m));
+  }
+}
+#define VPT_CNT(k) vpt_cnt(k)
+#else
+#define VPT_CNT(k)
+#endif
+enum { CNT_NODE = 0, CNT_PRIM, CNT_ENTER, CNT_OUTER, CNT_TRIP, CNT_POP, CNT_MISS, CNT_SURFACE, CNT_VOLUME, CNT_LIGHTS, CNT_GENERATE, CNT_LEAF };
+
 // (ref, t0) stack of one lane: the first `cap` entries live in LDS (entry-major: conflict-free), deeper
 // ones in a per-launch HBM array (entry-major too: coalesced).  `cap` covers what traversals use in
 // practice; the HBM part only makes the worst case (three pending siblings on every quad level) safe.
@@ -40,27 +57,29 @@ struct stack_cfg {
   int2*      mem;      // spill * lanes entries
   long long  lanes;    // lanes of the launch (= entry stride)
 };
+template <bool SPILL>
 struct lane_stack2 {
   int*      base;   // &lds[threadIdx.x]; entry e: ref at base[(2e)*VPT_BLOCK], t0 at base[(2e+1)*VPT_BLOCK]
   int       cap;
   int2*     deep;   // &mem[global lane]; entry cap + e at deep[e * lanes]
   long long lanes;
   VPT_DEV void push(int& sp, int ref, float t0) const {
-    if (sp < cap) base[(2 * sp) * VPT_BLOCK] = ref, base[(2 * sp + 1) * VPT_BLOCK] = __float_as_int(t0);
+    if (!SPILL || sp < cap) base[(2 * sp) * VPT_BLOCK] = ref, base[(2 * sp + 1) * VPT_BLOCK] = __float_as_int(t0);
     else deep[(sp - cap) * lanes] = make_int2(ref, __float_as_int(t0));
     sp++;
   }
   VPT_DEV void pop(int& sp, int& ref, float& t0) const {
     sp--;
-    if (sp < cap) ref = base[(2 * sp) * VPT_BLOCK], t0 = __int_as_float(base[(2 * sp + 1) * VPT_BLOCK]);
+    if (!SPILL || sp < cap) ref = base[(2 * sp) * VPT_BLOCK], t0 = __int_as_float(base[(2 * sp + 1) * VPT_BLOCK]);
     else {
       int2 e = deep[(sp - cap) * lanes];
       ref = e.x, t0 = __int_as_float(e.y);
     }
   }
 };
-VPT_DEV lane_stack2 make_lane_stack(int* lds, const stack_cfg& cfg) {
-  lane_stack2 stk;
+template <bool SPILL>
+VPT_DEV lane_stack2<SPILL> make_lane_stack(int* lds, const stack_cfg& cfg) {
+  lane_stack2<SPILL> stk;
   stk.base = lds + threadIdx.x, stk.cap = cfg.cap;
   stk.deep = cfg.mem + ((long long)blockIdx.x * VPT_BLOCK + threadIdx.x), stk.lanes = cfg.lanes;
   return stk;
@@ -112,7 +131,8 @@ VPT_DEV bool has_zero(f3 d) { return d.x == 0 || d.y == 0 || d.z == 0; }
 //      reference's shape-level loop does first, yocto_bvh.cpp:728-733); instances that miss it are
 //      skipped without ever leaving world space.
 #define VPT_NONE (-2147483647 - 1)
-VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const lane_stack2& stk) {
+template <class STK>
+VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const STK& stk) {
   hit_t r;
   r.instance = -1, r.element = -1, r.uv = mk2(0, 0), r.distance = 0, r.hit = false;
   const float tmin = VPT_RAY_EPS;
@@ -133,6 +153,7 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
     while (sp > base) {
       int   ref;
       float t0;
+      VPT_CNT(CNT_POP);
       stk.pop(sp, ref, t0);
       if (t0 <= tmax * VPT_BOX_K) return ref;
     }
@@ -141,6 +162,7 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
   // enter pending instances (pend = start<<4 | count) until one passes its root test; else pop
   // enter one instance from its 96-byte enter record (vpt_device.h); false if its root box is missed
   auto try_enter = [&](int slot) {
+    VPT_CNT(CNT_ENTER);
     const float4* e = sc.scene_enter + 6 * (long long)slot;
     float4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5];
     f3   lo, ld, linv;
@@ -184,8 +206,10 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
   }
 
   while (true) {
+    VPT_CNT(CNT_OUTER);
     // ---- phase A: internal (quad) nodes ----------------------------------------------------------------
     while (cur >= 0) {
+      VPT_CNT(CNT_NODE);
       const float4* q = wn + 8 * (long long)cur;
       float4 lx = q[0], ly = q[1], lz = q[2], hx = q[3], hy = q[4], hz = q[5], qr = q[6];
       int    meta = __float_as_int(q[7].x);
@@ -244,7 +268,9 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
     if (shape_base >= 0) {
       // ---- phase B: primitives of a shape leaf, in order -------------------------------------------------
       int start = code >> 4, num = code & 15;
+      VPT_CNT(CNT_LEAF);
       for (int k = 0; k < num; k++) {
+        VPT_CNT(CNT_PRIM);
         const float4* rec = leafs + 4 * (long long)(start + k);
         float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
         if (intersect_quad(co, cd, tmin, tmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), r.uv, r.distance))
@@ -328,11 +354,11 @@ enum { ST_NEW = 0, ST_MAIN = 1, ST_LPDF = 2 };
 #define VPT_WAVES_PER_SIMD 2
 #endif
 
-template <int SH>
+template <int SH, bool SPILL>
 __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel(DScene sc, DParams pr,
     float4* __restrict__ image, int* __restrict__ hits, ulonglong2* __restrict__ rngs, stack_cfg stack) {
   extern __shared__ int lds_stack[];
-  const lane_stack2 stk = make_lane_stack(lds_stack, stack);
+  const lane_stack2<SPILL> stk = make_lane_stack<SPILL>(lds_stack, stack);
 
   int slot = blockIdx.x * VPT_BLOCK + threadIdx.x;
   int px = 0, py = 0;
@@ -362,6 +388,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
   while (true) {
     if (state == ST_NEW) {
       if (sample == pr.nsamples) break;
+      VPT_CNT(CNT_GENERATE);
       const vpt_camera& cam = sc.cameras[pr.camera];
       float u, v;
       if (pr.preview) {
@@ -383,6 +410,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
       finish = true;
     } else {
       // ---- the one BVH query of this trip ---------------------------------------------------------
+      VPT_CNT(CNT_TRIP);
       bool  lpdf_query = HAS_MIS && state == ST_LPDF;
       int   qinst      = lpdf_query ? sc.lights[lp_light].instance : -1;
       hit_t h          = traverse(sc, lpdf_query ? lp_pos : ray.o, ray.d, qinst, stk);

@@ -6,7 +6,10 @@
 #include "vpt_device.h"
 #include "vpt_math.hip.h"
 
-#define VPT_BLOCK 256   // threads per workgroup: 4 wave64, one 8x8 pixel tile per wave
+#ifndef VPT_BLOCK
+#define VPT_BLOCK 64   // threads per workgroup = one wave64 = one 8x8 pixel tile: a wave that finishes frees its slot at once
+#endif
+
 
 // ------------------------------------------------------------------------------------------------
 // per-lane traversal stack in LDS: entry e of lane t lives at lds[e * VPT_BLOCK + t], so the 64

@@ -148,9 +148,10 @@ __global__ void __launch_bounds__(VPT_BLOCK) vpt_stream_begin(DScene sc, DParams
 }
 
 // ---- k_trace: one BVH query per queue entry ------------------------------------------------------------
+template <bool SPILL>
 __global__ void __launch_bounds__(VPT_BLOCK, 4) vpt_stream_trace(DScene sc, DPaths P, int q, stack_cfg stack) {
   extern __shared__ int lds_stack[];
-  const lane_stack2 stk = make_lane_stack(lds_stack, stack);
+  const lane_stack2<SPILL> stk = make_lane_stack<SPILL>(lds_stack, stack);
   if (blockIdx.x == 0 && threadIdx.x == 0) P.count[q ^ 1] = 0;   // the queue the next k_shade appends to
   int i = blockIdx.x * VPT_BLOCK + threadIdx.x;
   if (i >= P.count[q]) return;

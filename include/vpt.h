@@ -272,6 +272,13 @@ int vpt_resolve_device(const vpt_layout* layout, const void* d_tiles_all_ranks, 
 /* per-launch profile of the last vpt_render_device on this scene (HIP events on `stream`) */
 int vpt_last_kernel_ms(vpt_scene* scene, float* ms);
 
+/* Device self-test of an arithmetic shortcut the kernels rely on for bit-exact parity: the reference divides
+ * (1 / d per ray, yocto_bvh.cpp:806-808; 1 / det per triangle, yocto_geometry.h:690), the kernels use
+ * v_rcp_f32 + one Newton step where every lane's operand has a biased exponent in 1..250.  Runs all 2^32 bit
+ * patterns on `device` and returns in *mismatches how many in-range inputs differ from the IEEE quotient
+ * (must be 0), in *fallbacks how many patterns are out of range (handled by a real division). */
+int vpt_selftest_reciprocal(int device, unsigned long long* mismatches, unsigned long long* fallbacks);
+
 #ifdef __cplusplus
 }
 #endif

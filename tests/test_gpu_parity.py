@@ -236,3 +236,11 @@ def test_gpu_matches_reference_on_substitute_scenes(vpt, name):
     assert close.mean() >= 0.99
     m_g, m_r = g.image[..., :3].mean(), ref_img[..., :3].mean()
     assert abs(m_g - m_r) <= 0.05 * abs(m_r) + 1e-6
+
+
+def test_reciprocal_shortcut_is_exact_for_every_float(vpt):
+    """rcp + one Newton step must equal the IEEE quotient for every operand the kernels feed it (biased
+    exponent 1..250); the rest (zeros, denormals, >= 2^124, inf, NaN: 2 * (2^23 + 5 * 2^23) patterns) divide."""
+    bad, skipped = vpt.selftest_reciprocal(0)
+    assert bad == 0
+    assert skipped == 2 * 6 * (1 << 23)

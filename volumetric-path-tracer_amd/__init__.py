@@ -100,6 +100,7 @@ hip.vpt_state_download.argtypes = [C.POINTER(VptLayout), _p, _p, _p, _p, _p, _p,
 hip.vpt_render_device.argtypes = [_p, C.POINTER(VptParams), C.POINTER(VptLayout), C.c_int, _p, _p, _p, _p]
 hip.vpt_resolve_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
 hip.vpt_last_kernel_ms.argtypes = [_p, C.POINTER(C.c_float)]
+hip.vpt_selftest_reciprocal.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
 host.vpth_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
 host.vpth_scene_load.restype = _p
 host.vpth_scene_free.argtypes = [_p]
@@ -232,6 +233,13 @@ def resolve_device(layout: VptLayout, d_tiles_all: int, samples: int, d_rows: in
 def get_render(state: PathtraceState) -> np.ndarray:
     """get_render, yocto_pathtrace.cpp:1105-1116: image * (1/samples) in float32"""
     return state.image * np.float32(np.float32(1.0) / np.float32(state.samples))
+
+
+def selftest_reciprocal(device: int = 0):
+    """(mismatches, fallbacks) of the kernels' exact-reciprocal shortcut over all 2^32 floats (include/vpt.h)"""
+    bad, skipped = C.c_ulonglong(0), C.c_ulonglong(0)
+    _check(hip.vpt_selftest_reciprocal(device, C.byref(bad), C.byref(skipped)), "vpt_selftest_reciprocal")
+    return bad.value, skipped.value
 
 
 def linear_to_srgb8(image_sum: np.ndarray, samples: int) -> np.ndarray:

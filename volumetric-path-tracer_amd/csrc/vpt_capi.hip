@@ -12,6 +12,18 @@
 
 #include "vpt_stream_kernels.hip.h"
 
+// all 2^32 operands of rcp_newton (vpt_mesh_kernel.hip.h) against the IEEE quotient; out[0] = mismatches, out[1] = out of range
+__global__ void vpt_reciprocal_selftest_kernel(unsigned long long* out) {
+  unsigned long long bad = 0, skipped = 0;
+  for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32); b += (unsigned long long)gridDim.x * blockDim.x) {
+    float x = __uint_as_float((unsigned)b), a = __builtin_fabsf(x);
+    if (!rcp_in_range(a, a)) { skipped++; continue; }
+    if (__float_as_uint(rcp_newton(x)) != __float_as_uint(1.0f / x)) bad++;
+  }
+  if (bad) atomicAdd(&out[0], bad);
+  if (skipped) atomicAdd(&out[1], skipped);
+}
+
 namespace {
 
 thread_local std::string g_error;
@@ -744,6 +756,20 @@ int vpt_render(vpt_scene* s, const vpt_params* params, int nsamples, int width, 
   if (int rc = vpt_state_download(&lay, s->s_image, s->s_hits, s->s_rng, image_rgba, hits, rng, nullptr)) return rc;
   *samples_io += todo;
   return VPT_OK;
+}
+
+int vpt_selftest_reciprocal(int device, unsigned long long* mismatches, unsigned long long* fallbacks) {
+  if (!mismatches || !fallbacks) return fail(VPT_ERR_INVALID_ARG, "null argument");
+  HIP_TRY(hipSetDevice(device));
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 16));
+  HIP_TRY(hipMemset(d, 0, 16));
+  hipLaunchKernelGGL(vpt_reciprocal_selftest_kernel, dim3(4096), dim3(256), 0, 0, d);
+  unsigned long long h[2] = {0, 0};
+  int rc = hipMemcpy(h, d, 16, hipMemcpyDeviceToHost) == hipSuccess ? VPT_OK : fail(VPT_ERR_HIP, "reciprocal self-test failed to run");
+  (void)hipFree(d);
+  *mismatches = h[0], *fallbacks = h[1];
+  return rc;
 }
 
 #ifdef VPT_COUNTERS

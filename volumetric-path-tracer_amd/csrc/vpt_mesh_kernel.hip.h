@@ -103,6 +103,26 @@ VPT_DEV float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "
 VPT_DEV float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 VPT_DEV float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 VPT_DEV float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// 1/x bit-identical to the IEEE quotient 1.0f/x.  v_rcp_f32 followed by one Newton step is correctly
+// rounded for EVERY float whose biased exponent is 1..250 (2^-126 <= |x| < 2^124): checked exhaustively on
+// gfx950 by vpt_selftest_reciprocal() (tests/test_gpu_parity.py).  Other inputs (0, denormals, huge, inf,
+// NaN) take the division; the choice is made per wave so that only one of the two sequences is executed.
+VPT_DEV float rcp_newton(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+VPT_DEV bool rcp_in_range(float lo_abs, float hi_abs) { return lo_abs >= 0x1p-126f && hi_abs < 0x1p124f; }
+VPT_DEV float rcp_exact(float x) {
+  float a = __builtin_fabsf(x);
+  if (__builtin_amdgcn_ballot_w64(!rcp_in_range(a, a)) == 0) return rcp_newton(x);
+  return 1 / x;
+}
+VPT_DEV f3 rcp3_exact(f3 d) {
+  float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+  if (__builtin_amdgcn_ballot_w64(!rcp_in_range(hw_min3(ax, ay, az), hw_max3(ax, ay, az))) == 0)
+    return mk3(rcp_newton(d.x), rcp_newton(d.y), rcp_newton(d.z));
+  return mk3(1 / d.x, 1 / d.y, 1 / d.z);
+}
 // same test with 3-operand min/max; only valid when no product can be NaN (no zero in the direction):
 // min/max of non-NaN values do not depend on how they are associated, so the result is the reference's
 VPT_DEV bool box_pass_fast(f3 bmin, f3 bmax, f3 o, f3 dinv, float tmin, float tmax, float& t0) {
@@ -137,7 +157,7 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
   r.instance = -1, r.element = -1, r.uv = mk2(0, 0), r.distance = 0, r.hit = false;
   const float tmin = VPT_RAY_EPS;
   float tmax = VPT_FLT_MAX;
-  const f3   winv = mk3(1 / wd.x, 1 / wd.y, 1 / wd.z);
+  const f3   winv = rcp3_exact(wd);
   const int  wsgn = sign_bits(winv);
   const bool wslow = has_zero(wd);
   f3    co = wo, cd = wd, cinv = winv;
@@ -160,38 +180,38 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
     return VPT_NONE;
   };
   // enter pending instances (pend = start<<4 | count) until one passes its root test; else pop
-  // enter one instance from its 96-byte enter record (vpt_device.h); false if its root box is missed
-  auto try_enter = [&](int slot) {
-    VPT_CNT(CNT_ENTER);
-    const float4* e = sc.scene_enter + 6 * (long long)slot;
-    float4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5];
-    f3   lo, ld, linv;
-    bool lslow;
-    if (__float_as_int(e5.z) && !wslow) {
-      // inverse frame = {I, -o}: 1*d + 0*d' + 0*d'' == d bit for bit when no component is zero, and
-      // ((1*o.x + 0*o.y) + 0*o.z) + t == o.x + t: skip the 3x3 product and the three divisions
-      lo = mk3(wo.x + e2.y, wo.y + e2.z, wo.z + e2.w), ld = wd, linv = winv, lslow = false;
-    } else {
-      frame inv = unpack_frame(e0, e1, e2);
-      lo = transform_point(inv, wo), ld = transform_vector(inv, wd);
-      linv = mk3(1 / ld.x, 1 / ld.y, 1 / ld.z), lslow = has_zero(ld);
-    }
-    float t0;
-    if (!(__float_as_int(e5.w) && box_test(lslow, mk3(e3.x, e3.y, e3.z), mk3(e3.w, e4.x, e4.y), lo, linv, tmin, tmax, t0))) return false;
-    co = lo, cd = ld, cinv = linv, csgn = sign_bits(linv), slow = lslow;
-    cur_inst = __float_as_int(e5.y), shape_base = sp;
-    wn    = sc.shape_wnodes + 8 * (long long)__float_as_int(e4.w);
-    leafs = sc.leaf_prims + 4 * (long long)__float_as_int(e5.x);
-    cur   = __float_as_int(e4.z);   // the instance's root: visited next with the same tmax
-    return true;
-  };
-  // enter pending instances (pend = start<<4 | count) until one passes its root test; else pop
-  auto enter_next = [&]() {
+  // Phase C.  Enter the pending instances of a scene leaf (pend = first slot << 4 | count) one after another,
+  // from their 96-byte enter records (vpt_device.h), until one passes the root-box test the reference's
+  // shape-level loop does first (yocto_bvh.cpp:728-733); instances that miss it never leave world space.
+  // At scene level {cd, cinv, csgn, slow} always equal the world ray's, so an instance whose inverse frame
+  // is {I, -o} only needs co: 1*d + 0*d' + 0*d'' == d bit for bit when no component is zero, and
+  // ((1*o.x + 0*o.y) + 0*o.z) + t == o.x + t.  co itself is restored once, when the leaf is exhausted.
+  // Returns the lane's next reference.
+  auto enter_pending = [&]() {
     while (pend & 15) {
-      int slot = pend >> 4;
-      pend += 15;
-      if (try_enter(slot)) return cur;
+      VPT_CNT(CNT_ENTER);
+      const float4* e = sc.scene_enter + 6 * (long long)(pend >> 4);
+      pend += 15;   // first slot + 1, count - 1
+      float4 e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5];
+      bool   general = !__float_as_int(e5.z) || wslow;
+      if (general) {
+        frame inv = unpack_frame(e[0], e[1], e2);
+        co = transform_point(inv, wo), cd = transform_vector(inv, wd);
+        cinv = rcp3_exact(cd), slow = has_zero(cd);
+      } else {
+        co = mk3(wo.x + e2.y, wo.y + e2.z, wo.z + e2.w);
+      }
+      float t0;
+      if (__float_as_int(e5.w) && box_test(slow, mk3(e3.x, e3.y, e3.z), mk3(e3.w, e4.x, e4.y), co, cinv, tmin, tmax, t0)) {
+        if (general) csgn = sign_bits(cinv);
+        cur_inst = __float_as_int(e5.y), shape_base = sp;
+        wn    = sc.shape_wnodes + 8 * (long long)__float_as_int(e4.w);
+        leafs = sc.leaf_prims + 4 * (long long)__float_as_int(e5.x);
+        return __float_as_int(e4.z);   // the instance's root: visited next with the same tmax
+      }
+      if (general) cd = wd, cinv = winv, slow = wslow;
     }
+    co = wo;
     return pop_valid();
   };
 
@@ -201,7 +221,8 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
                                   mk3(sc.scene_root_hi_x, sc.scene_root_hi_y, sc.scene_root_hi_z), co, cinv, tmin, tmax, t0))
       cur = sc.scene_root_ref;
   } else {   // single-instance query (yocto_bvh.cpp:874-881)
-    if (!try_enter(sc.slot_of_instance[only_instance])) cur = VPT_NONE;
+    pend = (sc.slot_of_instance[only_instance] << 4) | 1;
+    cur  = enter_pending();
     shape_base = 0;
   }
 
@@ -258,9 +279,9 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
       if (shape_base < 0 || only_instance >= 0) break;   // nothing left: query finished
       // leaving an instance: back to world space, then its leaf's next instance or the next scene entry
       shape_base = -1;
-      co = wo, cd = wd, cinv = winv, csgn = wsgn, slow = wslow;
+      cd = wd, cinv = winv, csgn = wsgn, slow = wslow;   // co: enter_pending
       wn  = sc.scene_wnodes;
-      cur = enter_next();
+      cur = enter_pending();
       if (cur == VPT_NONE && shape_base < 0) break;
       continue;
     }
@@ -280,7 +301,7 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
     } else {
       // ---- phase C: a scene leaf: its instances are entered one after another, in order ---------------------
       pend = code;
-      cur  = enter_next();
+      cur  = enter_pending();
       if (cur == VPT_NONE && shape_base < 0) break;
     }
   }

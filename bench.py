@@ -21,6 +21,7 @@ The JSON line carries, besides the driver's contract:
                 bounded sample (default 640x267x96 spp, ~10 s) of the same workload.  Rank 0, N=1 only.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -151,8 +152,9 @@ def main():
         # memory-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
         # runs of this same command); only quoted for the workload it was measured on
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_v5_hbm_traffic.json")
-        if os.path.exists(tfile) and args.scene == SCENE and args.shader == "volpathtrace" and args.bounces == 64:
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))   # latest round's passes
+        tfile = tfiles[-1] if tfiles else ""
+        if tfile and args.scene == SCENE and args.shader == "volpathtrace" and args.bounces == 64:
             traffic = round(json.load(open(tfile))["bytes_per_sample"] * per_launch_samples)
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

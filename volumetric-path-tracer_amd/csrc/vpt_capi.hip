@@ -7,6 +7,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -492,7 +494,37 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   UP(upload(s, d.environments, d.num_environments, &D.environments));
   UP(upload(s, env_inv, &D.env_inv));
   UP(upload(s, d.lights, d.num_lights, &D.lights));
-  UP(upload(s, d.light_cdf, d.num_light_cdf, &D.light_cdf));
+  {
+    const float inf = std::numeric_limits<float>::infinity();
+    std::vector<DCdfIndex> index((size_t)d.num_lights);
+    std::vector<float>     pool;
+    for (int i = 0; i < d.num_lights; i++) {
+      DCdfIndex& ix = index[(size_t)i];
+      ix = {};
+      const float* c = d.light_cdf + d.lights[i].cdf_offset;
+      long long    n = d.lights[i].cdf_len;
+      bool sorted = n > 64;
+      for (long long k = 1; sorted && k < n; k++) sorted = c[k - 1] <= c[k];   // false for NaN too
+      if (!sorted) continue;
+      std::vector<float> level(c, c + n);
+      size_t mark = pool.size();
+      while (true) {
+        if (ix.levels == 8) { ix.levels = 0; break; }   // > 16^8 entries: keep the binary search
+        ix.offset[ix.levels++] = (int)pool.size();
+        ix.top_count = (int)level.size();
+        pool.insert(pool.end(), level.begin(), level.end());
+        pool.resize((pool.size() + 15) / 16 * 16, inf);
+        if (level.size() <= 16) break;
+        std::vector<float> up((level.size() + 15) / 16);
+        for (size_t g = 0; g < up.size(); g++) up[g] = level[std::min(level.size() - 1, 16 * g + 15)];
+        level.swap(up);
+      }
+      if (ix.levels == 0) pool.resize(mark);
+    }
+    UP(upload(s, d.light_cdf, d.num_light_cdf, &D.light_cdf));
+    UP(upload(s, index, &D.light_index));
+    UP(upload(s, pool, &D.light_index_pool));
+  }
   UP(upload(s, d.volumes, d.num_volumes, &D.volumes));
   UP(upload(s, d.voxels, d.num_voxels, &D.voxels));
   UP(upload(s, d.vol_instances, d.num_vol_instances, &D.vol_instances));

@@ -466,6 +466,14 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
         finish = true;
       } else {
         bool in_volume = false;
+        // a scattering event of pathtrace / volpathtrace is finished after the light sampling both event kinds
+        // share (one sample_lights for the lanes of either kind): 1 = surface, 2 = medium
+        int    scatter = 0;
+        bool   want_lights = false, vol_boundary = false;
+        f3     outgoing = -ray.d, position = mk3(0, 0, 0), normal = mk3(0, 0, 0), incoming = mk3(0, 0, 0);
+        f2     l_ruv = mk2(0, 0);
+        float  l_rel = 0, l_rl = 0;
+        mpoint m;
         if constexpr (SH == K_VOLPATH) {
           if (in_medium) {   // cpp:586-596 — rd is drawn before rl
             float rd       = rand1f(rng);
@@ -478,16 +486,14 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
         }
         if (!in_volume) {
           const DInstance& inst = sc.instances[h.instance];
-          f3     outgoing = -ray.d;
-          f3     position = eval_position(sc, inst, h.element, h.uv);
-          f3     normal   = eval_shading_normal(sc, inst, h.element, h.uv, outgoing);
-          mpoint m        = eval_material(sc, inst, h.element, h.uv);
+          position = eval_position(sc, inst, h.element, h.uv);
+          normal   = eval_shading_normal(sc, inst, h.element, h.uv, outgoing);
+          m        = eval_material(sc, inst, h.element, h.uv);
           if (m.opacity < 1 && rand1f(rng) >= m.opacity) {
             ray = make_ray(position + ray.d * 1e-2f, ray.d);   // bounce -= 1; continue
           } else {
             if (bounce == 0) alpha = 1;
             radiance = radiance + weight * eval_emission(m.emission, normal, outgoing);
-            f3 incoming = mk3(0, 0, 0);
             if constexpr (SH == K_EYELIGHT) {   // cpp:869-886
               incoming = outgoing;
               radiance = radiance + weight * VPT_PI * eval_bsdfcos(m, normal, outgoing, incoming);
@@ -522,7 +528,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
               }
               bounce++;
             } else {   // pathtrace / volpathtrace, cpp:619-651
-              bool vol_boundary = SH == K_VOLPATH && is_volumetric_type(sc.materials[inst.material].type);
+              vol_boundary = SH == K_VOLPATH && is_volumetric_type(sc.materials[inst.material].type);
               if (!is_delta(m)) {
                 if (rand1f(rng) < 0.5f) {
                   f2 rn;
@@ -531,23 +537,13 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
                   float rnl = rand1f(rng);
                   incoming  = sample_bsdfcos(m, normal, outgoing, rnl, rn);
                 } else {
-                  f2 ruv;
-                  ruv.x     = rand1f(rng);
-                  ruv.y     = rand1f(rng);
-                  float rel = rand1f(rng);
-                  float rl  = rand1f(rng);
-                  incoming  = sample_lights(sc, position, rl, rel, ruv);
+                  l_ruv.x = rand1f(rng);
+                  l_ruv.y = rand1f(rng);
+                  l_rel   = rand1f(rng);
+                  l_rl    = rand1f(rng);
+                  want_lights = true;
                 }
-                if (is_zero3(incoming)) finish = true;
-                else {
-                  mis_f      = eval_bsdfcos(m, normal, outgoing, incoming);
-                  mis_pdf    = sample_bsdfcos_pdf(m, normal, outgoing, incoming);
-                  mis_toggle = vol_boundary && dot(normal, outgoing) * dot(normal, incoming) < 0;
-                  if (mis_toggle && !in_medium)   // entering: the medium slot is free, fill it now
-                    med_density = m.density, med_scattering = m.scattering, med_emission = m.emission, med_g = m.scanisotropy;
-                  ray = make_ray(position, incoming);
-                  lp_sum = 0, lp_light = 0, advance_lights = true;
-                }
+                scatter = 1;
               } else {
                 float rnl = rand1f(rng);
                 incoming  = sample_delta(m, normal, outgoing, rnl);
@@ -567,10 +563,8 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
             }
           }
         } else if constexpr (SH == K_VOLPATH) {   // volume event, cpp:654-673
-          f3 outgoing = -ray.d;
-          f3 position = ray_point(ray, h.distance);
+          position = ray_point(ray, h.distance);
           radiance = radiance + weight * eval_emission(med_emission, position, outgoing);   // (sic) cpp:660
-          f3 incoming;
           if (rand1f(rng) < 0.5f) {
             f2 rn;
             rn.x = rand1f(rng);
@@ -578,18 +572,34 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
             (void)rand1f(rng);   // rnl is drawn and ignored, cpp:665
             incoming = sample_phasefunction(med_g, outgoing, rn);
           } else {
-            f2 ruv;
-            ruv.x     = rand1f(rng);
-            ruv.y     = rand1f(rng);
-            float rel = rand1f(rng);
-            float rl  = rand1f(rng);
-            incoming  = sample_lights(sc, position, rl, rel, ruv);
+            l_ruv.x = rand1f(rng);
+            l_ruv.y = rand1f(rng);
+            l_rel   = rand1f(rng);
+            l_rl    = rand1f(rng);
+            want_lights = true;
           }
-          mis_f      = med_density * med_scattering * eval_phasefunction(med_g, incoming, outgoing);
-          mis_pdf    = eval_phasefunction(med_g, outgoing, incoming);
-          mis_toggle = false;
-          ray        = make_ray(position, incoming);
-          lp_sum = 0, lp_light = 0, advance_lights = true;
+          scatter = 2;
+        }
+        if constexpr (HAS_MIS) {
+          if (want_lights) incoming = sample_lights(sc, position, l_rl, l_rel, l_ruv);
+          if (scatter == 1) {   // cpp:626-648
+            if (is_zero3(incoming)) finish = true;
+            else {
+              mis_f      = eval_bsdfcos(m, normal, outgoing, incoming);
+              mis_pdf    = sample_bsdfcos_pdf(m, normal, outgoing, incoming);
+              mis_toggle = vol_boundary && dot(normal, outgoing) * dot(normal, incoming) < 0;
+              if (mis_toggle && !in_medium)   // entering: the medium slot is free, fill it now
+                med_density = m.density, med_scattering = m.scattering, med_emission = m.emission, med_g = m.scanisotropy;
+              ray = make_ray(position, incoming);
+              lp_sum = 0, lp_light = 0, advance_lights = true;
+            }
+          } else if (scatter == 2) {   // cpp:666-671
+            mis_f      = med_density * med_scattering * eval_phasefunction(med_g, incoming, outgoing);
+            mis_pdf    = eval_phasefunction(med_g, outgoing, incoming);
+            mis_toggle = false;
+            ray        = make_ray(position, incoming);
+            lp_sum = 0, lp_light = 0, advance_lights = true;
+          }
         }
       }
 

@@ -426,6 +426,30 @@ VPT_DEV int sample_discrete(const float* cdf, int n, float r) {
   }
   return clampi(lo, 0, n - 1);
 }
+// entries of one 16-wide group that are <= r (the predicate of the binary search above), group given by its first element
+VPT_DEV int count_not_above(const float* g, float r) {
+  const float4* q = (const float4*)g;
+  float4 a = q[0], b = q[1], c = q[2], d = q[3];
+  return (int)!(r < a.x) + (int)!(r < a.y) + (int)!(r < a.z) + (int)!(r < a.w) + (int)!(r < b.x) + (int)!(r < b.y) +
+         (int)!(r < b.z) + (int)!(r < b.w) + (int)!(r < c.x) + (int)!(r < c.y) + (int)!(r < c.z) + (int)!(r < c.w) +
+         (int)!(r < d.x) + (int)!(r < d.y) + (int)!(r < d.z) + (int)!(r < d.w);
+}
+// the same index through the light's 16-ary levels (DCdfIndex, vpt_device.h)
+VPT_DEV int sample_light_cdf(const DScene& sc, int light_id, float r) {
+  const vpt_light& light = sc.lights[light_id];
+  const float*     cdf   = sc.light_cdf + light.cdf_offset;
+  const int        n     = light.cdf_len;
+  const DCdfIndex& ix    = sc.light_index[light_id];
+  if (ix.levels == 0) return sample_discrete(cdf, n, r);
+  float back = cdf[n - 1];
+  r = clampf(r * back, 0.0f, back - 0.00001f);
+  int idx = count_not_above(sc.light_index_pool + ix.offset[ix.levels - 1], r);
+  if (idx >= ix.top_count) return n - 1;   // no element above r: upper_bound == n, clamped
+  // the group found at one level holds an entry > r (its maximum is the entry just passed), so every level
+  // below finds its first entry > r inside that group; the +inf padding is never counted
+  for (int k = ix.levels - 2; k >= 0; k--) idx = 16 * idx + count_not_above(sc.light_index_pool + ix.offset[k] + 16 * (long long)idx, r);
+  return idx;
+}
 
 // ------------------------------------------------------------------------------------------------
 // BSDF lobes, yocto_shading.h:296-1039
@@ -945,12 +969,14 @@ VPT_DEV st_hit spheretrace(const DScene& sc, const ray_t& ray, int maxiter) {   
 VPT_DEV f3 sample_lights(const DScene& sc, f3 position, float rl, float rel, f2 ruv) {
   int       light_id = sample_uniform(sc.num_lights, rl);
   const vpt_light& light    = sc.lights[light_id];
-  const float* cdf   = sc.light_cdf + light.cdf_offset;
+  // the one CDF search of this call: emissive mesh -> element, textured environment -> texel
+  bool env_tex = light.instance == VPT_INVALID && light.sdf == VPT_INVALID && light.environment != VPT_INVALID &&
+                 sc.environments[light.environment].emission_tex != VPT_INVALID;
+  int  pick    = (light.instance != VPT_INVALID || env_tex) ? sample_light_cdf(sc, light_id, rel) : 0;
   if (light.instance != VPT_INVALID) {
     const DInstance& inst = sc.instances[light.instance];
-    int element = sample_discrete(cdf, light.cdf_len, rel);
     f2  uv      = sc.shapes[inst.shape].is_triangles ? mk2(1 - sqrtf(ruv.x), ruv.y * sqrtf(ruv.x)) : ruv;
-    return normalize(eval_position(sc, inst, element, uv) - position);
+    return normalize(eval_position(sc, inst, pick, uv) - position);
   } else if (light.sdf != VPT_INVALID) {
     const vpt_sdf& sdf = sc.sdfs[light.sdf];
     f3 wlightp  = transform_point(load_frame(sc.sdf_inv + 3 * light.sdf), mk3(ruv.x, ruv.y, 1) * ld3(sdf.whd));
@@ -959,8 +985,7 @@ VPT_DEV f3 sample_lights(const DScene& sc, f3 position, float rl, float rel, f2 
     const vpt_environment& env = sc.environments[light.environment];
     if (env.emission_tex != VPT_INVALID) {
       int tw = sc.textures[env.emission_tex].width, th = sc.textures[env.emission_tex].height;
-      int idx = sample_discrete(cdf, light.cdf_len, rel);
-      f2  uv  = mk2(((idx % tw) + 0.5f) / tw, ((idx / tw) + 0.5f) / th);
+      f2  uv  = mk2(((pick % tw) + 0.5f) / tw, ((pick / tw) + 0.5f) / th);
       return transform_direction(load_frame(env.frame),
           mk3(cosf(uv.x * 2 * VPT_PI) * sinf(uv.y * VPT_PI), cosf(uv.y * VPT_PI), sinf(uv.x * 2 * VPT_PI) * sinf(uv.y * VPT_PI)));
     }

@@ -14,6 +14,20 @@
 
 #include "vpt_stream_kernels.hip.h"
 
+// light_prims of the single-leaf mesh lights (vpt_device.h): one thread per (light, primitive of the leaf)
+__global__ void vpt_light_setup_kernel(DScene sc, float4* out) {
+  int l = blockIdx.x, k = threadIdx.x;
+  if (l >= sc.num_lights || k >= 4) return;
+  float4 r7 = sc.light_rec[8 * l + 7];
+  if ((__float_as_int(r7.w) & 255) != VPT_LIGHT_SMALL_MESH || k >= ((__float_as_int(r7.w) >> 8) & 15)) return;
+  const DInstance& inst = sc.instances[sc.lights[l].instance];
+  const DShape&    sh   = sc.shapes[inst.shape];
+  const float4*    leaf = sc.leaf_prims + 4 * ((long long)sh.leaf_offset + ((~sh.root_ref) >> 4) + k);
+  f3 n = eval_element_normal(sc, inst, __float_as_int(leaf[0].w));
+  for (int c = 0; c < 4; c++) out[20 * l + 5 * k + c] = leaf[c];
+  out[20 * l + 5 * k + 4] = make_float4(n.x, n.y, n.z, __int_as_float(sh.is_triangles ? 1 : 0));
+}
+
 // all 2^32 operands of rcp_newton (vpt_mesh_kernel.hip.h) against the IEEE quotient; out[0] = mismatches, out[1] = out of range
 __global__ void vpt_reciprocal_selftest_kernel(unsigned long long* out) {
   unsigned long long bad = 0, skipped = 0;
@@ -525,6 +539,37 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
     UP(upload(s, index, &D.light_index));
     UP(upload(s, pool, &D.light_index_pool));
   }
+  {
+    std::vector<float4> rec(8 * (size_t)d.num_lights, make_float4(0, 0, 0, 0));
+    for (int i = 0; i < d.num_lights; i++) {
+      const vpt_light& l = d.lights[i];
+      float4* r = &rec[8 * (size_t)i];
+      float   total = l.cdf_len > 0 ? d.light_cdf[l.cdf_offset + l.cdf_len - 1] : 0.0f;
+      int     kind = VPT_LIGHT_ENV_CONST, count = 0;
+      if (l.instance != VPT_INVALID) {
+        const DInstance& in = instances[(size_t)l.instance];
+        const DShape&    sh = shapes[(size_t)in.shape];
+        kind  = sh.root_ref < 0 ? VPT_LIGHT_SMALL_MESH : VPT_LIGHT_LARGE_MESH;
+        count = sh.root_ref < 0 ? ((~sh.root_ref) & 15) : 0;
+        for (int k = 0; k < 3; k++) r[k] = in.inv[k], r[3 + k] = in.fwd[k];
+        r[6] = make_float4(sh.root_box[0], sh.root_box[1], sh.root_box[2], total);
+        r[7] = make_float4(sh.root_box[3], sh.root_box[4], sh.root_box[5], 0);
+      } else if (l.sdf != VPT_INVALID) {
+        kind = VPT_LIGHT_SDF;
+      } else if (l.environment != VPT_INVALID && d.environments[l.environment].emission_tex != VPT_INVALID) {
+        kind = VPT_LIGHT_ENV_TEX;
+        const vpt_texture& t = d.textures[d.environments[l.environment].emission_tex];
+        for (int k = 0; k < 3; k++) r[k] = env_inv[3 * (size_t)l.environment + k];
+        int dims[2] = {t.width, t.height};
+        memcpy(&r[6].x, dims, 8);
+        r[6].z = total;
+      }
+      int tag = kind | (count << 8);
+      memcpy(&r[7].w, &tag, 4);
+    }
+    UP(upload(s, rec, &D.light_rec));
+    UP(upload(s, std::vector<float4>(20 * (size_t)d.num_lights, make_float4(0, 0, 0, 0)), &D.light_prims));
+  }
   UP(upload(s, d.volumes, d.num_volumes, &D.volumes));
   UP(upload(s, d.voxels, d.num_voxels, &D.voxels));
   UP(upload(s, d.vol_instances, d.num_vol_instances, &D.vol_instances));
@@ -540,6 +585,11 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
     if (per_cu > 4) per_cu = 4;   // __launch_bounds__(256, 4): 4 waves/SIMD = 4 workgroups/CU
     if (per_cu < 1) per_cu = 1;
     s->trace_blocks = prop.multiProcessorCount * per_cu;
+  }
+  if (d.num_lights > 0) {   // element normals of the single-leaf mesh lights, by the device's own eval_element_normal
+    hipLaunchKernelGGL(vpt_light_setup_kernel, dim3(d.num_lights), dim3(64), 0, 0, s->d, const_cast<float4*>(D.light_prims));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
   }
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));

@@ -48,6 +48,8 @@ struct DShape {          // 80 B
 // yocto_sampling.h:385-390) is unique on sorted data, so a top-down search over the levels returns the
 // reference's index with one 64-byte fetch per level instead of one dependent probe per bit (2 M-entry
 // environment CDF: 6 vs 21).
+enum { VPT_LIGHT_SMALL_MESH = 0, VPT_LIGHT_LARGE_MESH = 1, VPT_LIGHT_ENV_TEX = 2, VPT_LIGHT_ENV_CONST = 3, VPT_LIGHT_SDF = 4 };
+
 struct DCdfIndex {
   int levels;        // 0: no index (short or non-monotone CDF: plain binary search); else number of levels incl. level 0
   int top_count;     // valid entries of the top level
@@ -96,6 +98,15 @@ struct DScene {
   // lights
   const vpt_light* lights;
   const float*     light_cdf;
+  // Light records: what sample_lights_pdf needs per light, behind ONE index (light id) instead of the chain
+  // lights[] -> instances[] -> shapes[] -> leaf_prims[] -> elems[] -> positions[].  light_rec: 8 float4 per light:
+  // [0..2] inverse frame of the instance (mesh) / of the environment, [3..5] forward frame (mesh),
+  // [6] = {root box lo.xyz, area} (mesh) or {tex width, tex height (as int bits), cdf total, 0} (environment),
+  // [7] = {root box hi.xyz, kind | count << 8} with kind = VPT_LIGHT_*.  light_prims: for single-leaf mesh lights,
+  // 4 x 5 float4 per light: the leaf's primitives as corner positions (element id in p0.w) + the element's
+  // world-space normal (eval_element_normal), computed on the device at scene creation.
+  const float4*    light_rec;
+  const float4*    light_prims;
   const DCdfIndex* light_index;      // per light: 16-ary search index over its CDF (levels == 0: plain binary search)
   const float*     light_index_pool;
   // implicit surfaces

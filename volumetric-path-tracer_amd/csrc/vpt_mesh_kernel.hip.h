@@ -309,34 +309,38 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
 }
 
 // sample_lights_pdf's mesh-light walk (yocto_pathtrace.cpp:359-380) for a light whose shape BVH is a
-// single leaf: each hop is transform_ray + the root box test + <= 4 primitive tests, done inline.
-VPT_DEV float small_light_pdf(const DScene& sc, const vpt_light& light, f3 position, f3 direction) {
-  const DInstance& inst = sc.instances[light.instance];
-  const DShape&    sh   = sc.shapes[inst.shape];
-  frame  inv  = unpack_frame(inst.inv[0], inst.inv[1], inst.inv[2]);
-  f3     ld   = transform_vector(inv, direction);
-  f3     linv = mk3(1 / ld.x, 1 / ld.y, 1 / ld.z);
-  int    code = ~sh.root_ref;
-  const float4* leafs = sc.leaf_prims + 4 * ((long long)sh.leaf_offset + (code >> 4));
-  float area = sc.light_cdf[light.cdf_offset + light.cdf_len - 1];
-  float lpdf = 0.0f;
-  f3    next_position = position;
+// single leaf: each hop is transform_ray + the root box test + <= 4 primitive tests, done inline from the
+// light's record (DScene::light_rec / light_prims): every load depends on the light id only.
+VPT_DEV float small_light_pdf(const DScene& sc, int light_id, float4 r6, float4 r7, f3 position, f3 direction) {
+  const float4* rec   = sc.light_rec + 8 * (long long)light_id;
+  const float4* prims = sc.light_prims + 20 * (long long)light_id;
+  frame  inv   = unpack_frame(rec[0], rec[1], rec[2]);
+  f3     ld    = transform_vector(inv, direction);
+  f3     linv  = rcp3_exact(ld);
+  bool   lslow = has_zero(ld);
+  int    count = (__float_as_int(r7.w) >> 8) & 15;
+  float  area  = r6.w;
+  float  lpdf  = 0.0f;
+  f3     next_position = position;
   for (int hop = 0; hop < 100; hop++) {
     f3    lo   = transform_point(inv, next_position);
     float tmax = VPT_FLT_MAX, t0;
-    if (!box_pass(ld3(sh.root_box), ld3(sh.root_box + 3), lo, linv, VPT_RAY_EPS, tmax, t0)) break;
-    bool hit = false;
-    int  element = -1;
-    f2   uv = mk2(0, 0);
+    if (!box_test(lslow, mk3(r6.x, r6.y, r6.z), mk3(r7.x, r7.y, r7.z), lo, linv, VPT_RAY_EPS, tmax, t0)) break;
+    int   kh = -1;
+    f2    uv = mk2(0, 0);
     float dist = 0;
-    for (int k = 0; k < (code & 15); k++) {
-      float4 r0 = leafs[4 * k], r1 = leafs[4 * k + 1], r2 = leafs[4 * k + 2], r3 = leafs[4 * k + 3];
-      if (intersect_quad(lo, ld, VPT_RAY_EPS, tmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), uv, dist))
-        hit = true, element = __float_as_int(r0.w), tmax = dist;
+    for (int k = 0; k < count; k++) {
+      float4 c0 = prims[5 * k], c1 = prims[5 * k + 1], c2 = prims[5 * k + 2], c3 = prims[5 * k + 3];
+      if (intersect_quad(lo, ld, VPT_RAY_EPS, tmax, xyz(c0), xyz(c1), xyz(c2), xyz(c3), uv, dist)) kh = k, tmax = dist;
     }
-    if (!hit) break;
-    f3 lposition = eval_position(sc, inst, element, uv);
-    f3 lnormal   = eval_element_normal(sc, inst, element);
+    if (kh < 0) break;
+    // eval_position (yocto_scene.cpp:279-303) from the hit primitive's own corners: a triangle repeats its last corner
+    float4 c0 = prims[5 * kh], c1 = prims[5 * kh + 1], c2 = prims[5 * kh + 2], c3 = prims[5 * kh + 3], cn = prims[5 * kh + 4];
+    bool   tri = __float_as_int(cn.w) != 0;   // the shape holds triangles (interpolate_triangle), not quads
+    f3     lp  = tri ? tri_lerp(xyz(c0), xyz(c1), xyz(c2), uv)
+                     : (uv.x + uv.y <= 1 ? tri_lerp(xyz(c0), xyz(c1), xyz(c3), uv) : tri_lerp(xyz(c2), xyz(c3), xyz(c1), 1 - uv));
+    f3 lposition = transform_point(unpack_frame(rec[3], rec[4], rec[5]), lp);
+    f3 lnormal   = xyz(cn);
     lpdf += distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * area);
     next_position = lposition + direction * 1e-3f;
   }
@@ -344,25 +348,26 @@ VPT_DEV float small_light_pdf(const DScene& sc, const vpt_light& light, f3 posit
 }
 
 // pdf of the non-mesh lights (environment / sdf), one light: yocto_pathtrace.cpp:381-417
-VPT_DEV float other_light_pdf(const DScene& sc, const vpt_light& light, f3 position, f3 direction, int maxiter) {
-  const float* cdf = sc.light_cdf + light.cdf_offset;
-  if (light.sdf != VPT_INVALID) {
+VPT_DEV float other_light_pdf(const DScene& sc, int light_id, int kind, float4 r6, f3 position, f3 direction, int maxiter) {
+  if (kind == VPT_LIGHT_ENV_CONST) return 1 / (4 * VPT_PI);
+  const vpt_light& light = sc.lights[light_id];
+  const float*     cdf   = sc.light_cdf + light.cdf_offset;
+  if (kind == VPT_LIGHT_SDF) {
     st_hit h = spheretrace_one(sc, position, direction, light.sdf, maxiter);
     if (!h.hit) return 0;
     f3 lposition = position + direction * h.dist;
     f3 lnormal   = eval_sdf_normal_function(sc.sdfs[h.sdf], position, h.dist);
     return distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * cdf[light.cdf_len - 1]);
   }
-  if (light.environment != VPT_INVALID) {
-    const vpt_environment& env = sc.environments[light.environment];
-    if (env.emission_tex == VPT_INVALID) return 1 / (4 * VPT_PI);
-    int tw = sc.textures[env.emission_tex].width, th = sc.textures[env.emission_tex].height;
-    f3 wl = transform_direction(load_frame(sc.env_inv + 3 * light.environment), direction);
+  if (kind == VPT_LIGHT_ENV_TEX) {
+    const float4* rec = sc.light_rec + 8 * (long long)light_id;
+    int tw = __float_as_int(r6.x), th = __float_as_int(r6.y);
+    f3 wl = transform_direction(unpack_frame(rec[0], rec[1], rec[2]), direction);
     f2 tc = mk2(atan2f(wl.z, wl.x) / (2 * VPT_PI), acosf(clampf(wl.y, -1.0f, 1.0f)) / VPT_PI);
     if (tc.x < 0) tc.x += 1;
     int i = clampi((int)(tc.x * tw), 0, tw - 1), j = clampi((int)(tc.y * th), 0, th - 1);
     int idx = j * tw + i;
-    float prob  = (idx == 0 ? cdf[0] : cdf[idx] - cdf[idx - 1]) / cdf[light.cdf_len - 1];
+    float prob  = (idx == 0 ? cdf[0] : cdf[idx] - cdf[idx - 1]) / r6.z;
     float angle = (2 * VPT_PI / tw) * (VPT_PI / th) * sinf(VPT_PI * (j + 0.5f) / th);
     return prob / angle;
   }
@@ -607,16 +612,15 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
         if (advance_lights) {   // sample_lights_pdf's loop over lights, resumable (cpp:353-421)
           state = ST_MAIN;
           while (lp_light < sc.num_lights) {
-            const vpt_light& light = sc.lights[lp_light];
-            if (light.instance != VPT_INVALID) {
-              if (sc.shapes[sc.instances[light.instance].shape].root_ref < 0) {   // single-leaf shape: inline walk
-                lp_sum += small_light_pdf(sc, light, ray.o, ray.d);
-              } else {   // needs real BVH hops: hand over to the traversal (extra trips)
-                lp_cur = 0, lp_hop = 0, lp_pos = ray.o, state = ST_LPDF;
-                break;
-              }
+            float4 r6 = sc.light_rec[8 * lp_light + 6], r7 = sc.light_rec[8 * lp_light + 7];
+            int    kind = __float_as_int(r7.w) & 255;
+            if (kind == VPT_LIGHT_SMALL_MESH) {   // single-leaf shape: inline walk
+              lp_sum += small_light_pdf(sc, lp_light, r6, r7, ray.o, ray.d);
+            } else if (kind == VPT_LIGHT_LARGE_MESH) {   // needs real BVH hops: hand over to the traversal (extra trips)
+              lp_cur = 0, lp_hop = 0, lp_pos = ray.o, state = ST_LPDF;
+              break;
             } else {
-              lp_sum += other_light_pdf(sc, light, ray.o, ray.d, pr.spheretrace_maxiter);
+              lp_sum += other_light_pdf(sc, lp_light, kind, r6, ray.o, ray.d, pr.spheretrace_maxiter);
             }
             lp_light++;
           }

@@ -182,13 +182,11 @@ VPT_DEV float general_light_pdf(const DScene& sc, const vpt_light& light, f3 pos
 VPT_DEV float lights_pdf(const DScene& sc, const DParams& pr, f3 position, f3 direction, const lane_stack& stk) {
   float pdf = 0.0f;   // sample_lights_pdf, yocto_pathtrace.cpp:353-421
   for (int l = 0; l < sc.num_lights; l++) {
-    const vpt_light& light = sc.lights[l];
-    if (light.instance != VPT_INVALID) {
-      if (sc.shapes[sc.instances[light.instance].shape].root_ref < 0) pdf += small_light_pdf(sc, light, position, direction);
-      else pdf += general_light_pdf(sc, light, position, direction, stk);
-    } else {
-      pdf += other_light_pdf(sc, light, position, direction, pr.spheretrace_maxiter);
-    }
+    float4 r6 = sc.light_rec[8 * l + 6], r7 = sc.light_rec[8 * l + 7];
+    int    kind = __float_as_int(r7.w) & 255;
+    if (kind == VPT_LIGHT_SMALL_MESH) pdf += small_light_pdf(sc, l, r6, r7, position, direction);
+    else if (kind == VPT_LIGHT_LARGE_MESH) pdf += general_light_pdf(sc, sc.lights[l], position, direction, stk);
+    else pdf += other_light_pdf(sc, l, kind, r6, position, direction, pr.spheretrace_maxiter);
   }
   return pdf * ((float)1 / (float)sc.num_lights);
 }

@@ -19,3 +19,9 @@ print(f"{'section':20s} {'wave-exec/sample-slot':>22s} {'lane-exec/sample':>18s}
 for k, n in enumerate(names):
     w, l = out[2 * k], out[2 * k + 1]
     if w: print(f"{n:20s} {w / slots:22.2f} {l / nsamp:18.2f} {l / w:10.1f}")
+
+tn = ['A node loops', 'B prim phases', 'C instance entry', 'whole query', 'trip', 'lights pdf loop + MIS', 'sample_lights', 'surface', 'volume', 'generate', 'kernel']
+tot = out[32 + 10]
+print()
+for k, n in enumerate(tn):
+    if out[32 + k]: print(f"{n:24s} {100.0 * out[32 + k] / tot:6.2f} % of wave time")

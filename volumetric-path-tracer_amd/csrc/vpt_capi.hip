@@ -545,7 +545,7 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
       const vpt_light& l = d.lights[i];
       float4* r = &rec[8 * (size_t)i];
       float   total = l.cdf_len > 0 ? d.light_cdf[l.cdf_offset + l.cdf_len - 1] : 0.0f;
-      int     kind = VPT_LIGHT_ENV_CONST, count = 0;
+      int     kind = VPT_LIGHT_NONE, count = 0;
       if (l.instance != VPT_INVALID) {
         const DInstance& in = instances[(size_t)l.instance];
         const DShape&    sh = shapes[(size_t)in.shape];
@@ -556,10 +556,13 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
         r[7] = make_float4(sh.root_box[3], sh.root_box[4], sh.root_box[5], 0);
       } else if (l.sdf != VPT_INVALID) {
         kind = VPT_LIGHT_SDF;
-      } else if (l.environment != VPT_INVALID && d.environments[l.environment].emission_tex != VPT_INVALID) {
+      } else if (l.environment != VPT_INVALID && d.environments[l.environment].emission_tex == VPT_INVALID) {
+        kind = VPT_LIGHT_ENV_CONST;
+      } else if (l.environment != VPT_INVALID) {
         kind = VPT_LIGHT_ENV_TEX;
         const vpt_texture& t = d.textures[d.environments[l.environment].emission_tex];
         for (int k = 0; k < 3; k++) r[k] = env_inv[3 * (size_t)l.environment + k];
+        pack_frame(to_h(d.environments[l.environment].frame), &r[3]);
         int dims[2] = {t.width, t.height};
         memcpy(&r[6].x, dims, 8);
         r[6].z = total;

@@ -48,7 +48,7 @@ struct DShape {          // 80 B
 // yocto_sampling.h:385-390) is unique on sorted data, so a top-down search over the levels returns the
 // reference's index with one 64-byte fetch per level instead of one dependent probe per bit (2 M-entry
 // environment CDF: 6 vs 21).
-enum { VPT_LIGHT_SMALL_MESH = 0, VPT_LIGHT_LARGE_MESH = 1, VPT_LIGHT_ENV_TEX = 2, VPT_LIGHT_ENV_CONST = 3, VPT_LIGHT_SDF = 4 };
+enum { VPT_LIGHT_SMALL_MESH = 0, VPT_LIGHT_LARGE_MESH = 1, VPT_LIGHT_ENV_TEX = 2, VPT_LIGHT_ENV_CONST = 3, VPT_LIGHT_SDF = 4, VPT_LIGHT_NONE = 5 };
 
 struct DCdfIndex {
   int levels;        // 0: no index (short or non-monotone CDF: plain binary search); else number of levels incl. level 0
@@ -100,7 +100,7 @@ struct DScene {
   const float*     light_cdf;
   // Light records: what sample_lights_pdf needs per light, behind ONE index (light id) instead of the chain
   // lights[] -> instances[] -> shapes[] -> leaf_prims[] -> elems[] -> positions[].  light_rec: 8 float4 per light:
-  // [0..2] inverse frame of the instance (mesh) / of the environment, [3..5] forward frame (mesh),
+  // [0..2] inverse frame of the instance (mesh) / of the environment, [3..5] forward frame (mesh / environment),
   // [6] = {root box lo.xyz, area} (mesh) or {tex width, tex height (as int bits), cdf total, 0} (environment),
   // [7] = {root box hi.xyz, kind | count << 8} with kind = VPT_LIGHT_*.  light_prims: for single-leaf mesh lights,
   // 4 x 5 float4 per light: the leaf's primitives as corner positions (element id in p0.w) + the element's

@@ -43,9 +43,21 @@ VPT_DEV void vpt_cnt(int k) {
   }
 }
 #define VPT_CNT(k) vpt_cnt(k)
+// wave-level elapsed cycles per section: slot 32 + k of g_vpt_cnt (accumulated in LDS, flushed at kernel end)
+__shared__ unsigned long long s_vpt_time[16];
+VPT_DEV void vpt_time_add(int k, unsigned long long t0) {
+  unsigned long long dt = __builtin_readcyclecounter() - t0;
+  unsigned long long m  = __builtin_amdgcn_ballot_w64(true);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&s_vpt_time[k], dt);
+}
+#define VPT_T0(k) unsigned long long vpt_t0_##k = __builtin_readcyclecounter()
+#define VPT_T1(k) vpt_time_add(k, vpt_t0_##k)
 #else
 #define VPT_CNT(k)
+#define VPT_T0(k)
+#define VPT_T1(k)
 #endif
+enum { TM_NODES = 0, TM_PRIMS, TM_ENTER, TM_QUERY, TM_TRIP, TM_LIGHTS_PDF, TM_SAMPLE_LIGHTS, TM_SURFACE, TM_VOLUME, TM_GENERATE, TM_KERNEL };
 enum { CNT_NODE = 0, CNT_PRIM, CNT_ENTER, CNT_OUTER, CNT_TRIP, CNT_POP, CNT_MISS, CNT_SURFACE, CNT_VOLUME, CNT_LIGHTS, CNT_GENERATE, CNT_LEAF };
 
 // (ref, t0) stack of one lane: the first `cap` entries live in LDS (entry-major: conflict-free), deeper
@@ -229,6 +241,7 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
   while (true) {
     VPT_CNT(CNT_OUTER);
     // ---- phase A: internal (quad) nodes ----------------------------------------------------------------
+    VPT_T0(TM_NODES);
     while (cur >= 0) {
       VPT_CNT(CNT_NODE);
       const float4* q = wn + 8 * (long long)cur;
@@ -275,13 +288,16 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
       }
       cur = next != VPT_NONE ? next : pop_valid();
     }
+    VPT_T1(TM_NODES);
     if (cur == VPT_NONE) {
       if (shape_base < 0 || only_instance >= 0) break;   // nothing left: query finished
       // leaving an instance: back to world space, then its leaf's next instance or the next scene entry
       shape_base = -1;
       cd = wd, cinv = winv, csgn = wsgn, slow = wslow;   // co: enter_pending
       wn  = sc.scene_wnodes;
+      VPT_T0(TM_ENTER);
       cur = enter_pending();
+      VPT_T1(TM_ENTER);
       if (cur == VPT_NONE && shape_base < 0) break;
       continue;
     }
@@ -290,6 +306,7 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
       // ---- phase B: primitives of a shape leaf, in order -------------------------------------------------
       int start = code >> 4, num = code & 15;
       VPT_CNT(CNT_LEAF);
+      VPT_T0(TM_PRIMS);
       for (int k = 0; k < num; k++) {
         VPT_CNT(CNT_PRIM);
         const float4* rec = leafs + 4 * (long long)(start + k);
@@ -298,10 +315,13 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
           r.hit = true, r.element = __float_as_int(r0.w), r.instance = cur_inst, tmax = r.distance;
       }
       cur = pop_valid();
+      VPT_T1(TM_PRIMS);
     } else {
       // ---- phase C: a scene leaf: its instances are entered one after another, in order ---------------------
       pend = code;
+      VPT_T0(TM_ENTER);
       cur  = enter_pending();
+      VPT_T1(TM_ENTER);
       if (cur == VPT_NONE && shape_base < 0) break;
     }
   }
@@ -385,6 +405,9 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
     float4* __restrict__ image, int* __restrict__ hits, ulonglong2* __restrict__ rngs, stack_cfg stack) {
   extern __shared__ int lds_stack[];
   const lane_stack2<SPILL> stk = make_lane_stack<SPILL>(lds_stack, stack);
+#ifdef VPT_COUNTERS
+  if (threadIdx.x < 16) s_vpt_time[threadIdx.x] = 0;
+#endif
 
   int slot = blockIdx.x * VPT_BLOCK + threadIdx.x;
   int px = 0, py = 0;
@@ -411,6 +434,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
   int   lp_light = 0, lp_hop = 0;
   bool  mis_toggle = false;
 
+  VPT_T0(TM_KERNEL);
   while (true) {
     if (state == ST_NEW) {
       if (sample == pr.nsamples) break;
@@ -439,7 +463,9 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
       VPT_CNT(CNT_TRIP);
       bool  lpdf_query = HAS_MIS && state == ST_LPDF;
       int   qinst      = lpdf_query ? sc.lights[lp_light].instance : -1;
+      VPT_T0(TM_QUERY);
       hit_t h          = traverse(sc, lpdf_query ? lp_pos : ray.o, ray.d, qinst, stk);
+      VPT_T1(TM_QUERY);
 
       bool advance_lights = false;   // continue the light-pdf walk at lp_light
       if (lpdf_query) {
@@ -586,7 +612,9 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
           scatter = 2;
         }
         if constexpr (HAS_MIS) {
+          VPT_T0(TM_SAMPLE_LIGHTS);
           if (want_lights) incoming = sample_lights(sc, position, l_rl, l_rel, l_ruv);
+          VPT_T1(TM_SAMPLE_LIGHTS);
           if (scatter == 1) {   // cpp:626-648
             if (is_zero3(incoming)) finish = true;
             else {
@@ -610,6 +638,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
 
       if constexpr (HAS_MIS) {
         if (advance_lights) {   // sample_lights_pdf's loop over lights, resumable (cpp:353-421)
+          VPT_T0(TM_LIGHTS_PDF);
           state = ST_MAIN;
           while (lp_light < sc.num_lights) {
             float4 r6 = sc.light_rec[8 * lp_light + 6], r7 = sc.light_rec[8 * lp_light + 7];
@@ -631,6 +660,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
             if (!survive(weight, bounce, rng)) finish = true;
             bounce++;
           }
+          VPT_T1(TM_LIGHTS_PDF);
         }
       }
     }
@@ -644,6 +674,11 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
     }
   }
 
+  VPT_T1(TM_KERNEL);
+#ifdef VPT_COUNTERS
+  if ((threadIdx.x & 63) == 0)   // lane 0 owns a pixel whenever the wave does (padding lanes sit at the end)
+    for (int k = 0; k < 16; k++) atomicAdd(&g_vpt_cnt[32 + k], s_vpt_time[k]);
+#endif
   image[slot] = make_float4(acc.x, acc.y, acc.z, acc.w);
   hits[slot] += pr.nsamples;
   ulonglong2 r_out;

@@ -967,28 +967,39 @@ VPT_DEV st_hit spheretrace(const DScene& sc, const ray_t& ray, int maxiter) {   
 // lights, yocto_pathtrace.cpp:312-421
 // ------------------------------------------------------------------------------------------------
 VPT_DEV f3 sample_lights(const DScene& sc, f3 position, float rl, float rel, f2 ruv) {
-  int       light_id = sample_uniform(sc.num_lights, rl);
-  const vpt_light& light    = sc.lights[light_id];
+  int           light_id = sample_uniform(sc.num_lights, rl);
+  const float4* rec      = sc.light_rec + 8 * (long long)light_id;   // vpt_device.h: everything behind the light id
+  float4        r6 = rec[6], r7 = rec[7];
+  int           kind = __float_as_int(r7.w) & 255;
   // the one CDF search of this call: emissive mesh -> element, textured environment -> texel
-  bool env_tex = light.instance == VPT_INVALID && light.sdf == VPT_INVALID && light.environment != VPT_INVALID &&
-                 sc.environments[light.environment].emission_tex != VPT_INVALID;
-  int  pick    = (light.instance != VPT_INVALID || env_tex) ? sample_light_cdf(sc, light_id, rel) : 0;
-  if (light.instance != VPT_INVALID) {
-    const DInstance& inst = sc.instances[light.instance];
+  int pick = (kind == VPT_LIGHT_SMALL_MESH || kind == VPT_LIGHT_LARGE_MESH || kind == VPT_LIGHT_ENV_TEX) ? sample_light_cdf(sc, light_id, rel) : 0;
+  if (kind == VPT_LIGHT_SMALL_MESH) {
+    // eval_position (yocto_scene.cpp:279-303) from the light's own copy of its <= 4 primitives
+    const float4* prims = sc.light_prims + 20 * (long long)light_id;
+    int k = 0;
+    for (int j = 1; j < ((__float_as_int(r7.w) >> 8) & 15); j++)
+      if (__float_as_int(prims[5 * j].w) == pick) k = j;
+    float4 c0 = prims[5 * k], c1 = prims[5 * k + 1], c2 = prims[5 * k + 2], c3 = prims[5 * k + 3], cn = prims[5 * k + 4];
+    bool   tri = __float_as_int(cn.w) != 0;
+    f2     uv  = tri ? mk2(1 - sqrtf(ruv.x), ruv.y * sqrtf(ruv.x)) : ruv;
+    f3     lp  = tri ? tri_lerp(xyz(c0), xyz(c1), xyz(c2), uv)
+                     : (uv.x + uv.y <= 1 ? tri_lerp(xyz(c0), xyz(c1), xyz(c3), uv) : tri_lerp(xyz(c2), xyz(c3), xyz(c1), 1 - uv));
+    return normalize(transform_point(unpack_frame(rec[3], rec[4], rec[5]), lp) - position);
+  } else if (kind == VPT_LIGHT_LARGE_MESH) {
+    const DInstance& inst = sc.instances[sc.lights[light_id].instance];
     f2  uv      = sc.shapes[inst.shape].is_triangles ? mk2(1 - sqrtf(ruv.x), ruv.y * sqrtf(ruv.x)) : ruv;
     return normalize(eval_position(sc, inst, pick, uv) - position);
-  } else if (light.sdf != VPT_INVALID) {
-    const vpt_sdf& sdf = sc.sdfs[light.sdf];
-    f3 wlightp  = transform_point(load_frame(sc.sdf_inv + 3 * light.sdf), mk3(ruv.x, ruv.y, 1) * ld3(sdf.whd));
+  } else if (kind == VPT_LIGHT_SDF) {
+    int sdf_id = sc.lights[light_id].sdf;
+    const vpt_sdf& sdf = sc.sdfs[sdf_id];
+    f3 wlightp  = transform_point(load_frame(sc.sdf_inv + 3 * sdf_id), mk3(ruv.x, ruv.y, 1) * ld3(sdf.whd));
     return normalize(wlightp - position);
-  } else if (light.environment != VPT_INVALID) {
-    const vpt_environment& env = sc.environments[light.environment];
-    if (env.emission_tex != VPT_INVALID) {
-      int tw = sc.textures[env.emission_tex].width, th = sc.textures[env.emission_tex].height;
-      f2  uv  = mk2(((pick % tw) + 0.5f) / tw, ((pick / tw) + 0.5f) / th);
-      return transform_direction(load_frame(env.frame),
-          mk3(cosf(uv.x * 2 * VPT_PI) * sinf(uv.y * VPT_PI), cosf(uv.y * VPT_PI), sinf(uv.x * 2 * VPT_PI) * sinf(uv.y * VPT_PI)));
-    }
+  } else if (kind == VPT_LIGHT_ENV_TEX) {
+    int tw = __float_as_int(r6.x), th = __float_as_int(r6.y);
+    f2  uv = mk2(((pick % tw) + 0.5f) / tw, ((pick / tw) + 0.5f) / th);
+    return transform_direction(unpack_frame(rec[3], rec[4], rec[5]),
+        mk3(cosf(uv.x * 2 * VPT_PI) * sinf(uv.y * VPT_PI), cosf(uv.y * VPT_PI), sinf(uv.x * 2 * VPT_PI) * sinf(uv.y * VPT_PI)));
+  } else if (kind == VPT_LIGHT_ENV_CONST) {
     return sample_sphere(ruv);
   }
   return mk3(0, 0, 0);

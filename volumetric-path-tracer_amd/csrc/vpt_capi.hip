@@ -512,6 +512,7 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
     const float inf = std::numeric_limits<float>::infinity();
     std::vector<DCdfIndex> index((size_t)d.num_lights);
     std::vector<float>     pool;
+    std::vector<int2>      guide;
     for (int i = 0; i < d.num_lights; i++) {
       DCdfIndex& ix = index[(size_t)i];
       ix = {};
@@ -527,17 +528,32 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
         ix.offset[ix.levels++] = (int)pool.size();
         ix.top_count = (int)level.size();
         pool.insert(pool.end(), level.begin(), level.end());
-        pool.resize((pool.size() + 15) / 16 * 16, inf);
+        pool.resize((pool.size() + 15) / 16 * 16 + (ix.levels == 1 ? 16 : 0), inf);   // level 0 is also read 16-wide from any index
         if (level.size() <= 16) break;
         std::vector<float> up((level.size() + 15) / 16);
         for (size_t g = 0; g < up.size(); g++) up[g] = level[std::min(level.size() - 1, 16 * g + 15)];
         level.swap(up);
       }
-      if (ix.levels == 0) pool.resize(mark);
+      if (ix.levels == 0) { pool.resize(mark); continue; }
+      // guide table: n/4 buckets over [0, back); bracket = upper_bound of a lower / an upper bound of the bucket's r
+      float back = c[n - 1];
+      long long M = n / 4;
+      float scale = (float)M / back;
+      if (!(back > 0) || !std::isfinite(scale) || M < 16) continue;
+      ix.guide_offset = (int)guide.size(), ix.guide_buckets = (int)M, ix.guide_scale = scale;
+      for (long long b = 0; b < M; b++) {
+        // fl(r * scale) in [b, b+1)  =>  r in [b (1 - 2^-24) / scale, (b+1) (1 + 2^-23) / scale]; widened further
+        double lo_r = (double)b * (1.0 - 1.0 / 8388608.0) / (double)scale, hi_r = (double)(b + 1) * (1.0 + 1.0 / 4194304.0) / (double)scale;
+        float  lf = std::nextafter((float)lo_r, -inf), hf = std::nextafter((float)hi_r, inf);
+        int lo = b == 0 ? 0 : (int)(std::upper_bound(c, c + n, lf) - c);
+        int hi = b == M - 1 ? (int)n : (int)(std::upper_bound(c, c + n, hf) - c);
+        guide.push_back(make_int2(lo, hi));
+      }
     }
     UP(upload(s, d.light_cdf, d.num_light_cdf, &D.light_cdf));
     UP(upload(s, index, &D.light_index));
     UP(upload(s, pool, &D.light_index_pool));
+    UP(upload(s, guide, &D.light_guide));
   }
   {
     std::vector<float4> rec(8 * (size_t)d.num_lights, make_float4(0, 0, 0, 0));

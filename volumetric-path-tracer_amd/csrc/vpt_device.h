@@ -50,10 +50,18 @@ struct DShape {          // 80 B
 // environment CDF: 6 vs 21).
 enum { VPT_LIGHT_SMALL_MESH = 0, VPT_LIGHT_LARGE_MESH = 1, VPT_LIGHT_ENV_TEX = 2, VPT_LIGHT_ENV_CONST = 3, VPT_LIGHT_SDF = 4, VPT_LIGHT_NONE = 5 };
 
+// On top of it a guide table (the "cutpoint" method): the clamped sample r falls into bucket
+// b = min(int(r * guide_scale), guide_buckets - 1); light_guide[guide_offset + b] = {lo, hi} brackets
+// upper_bound for every r of that bucket (bounds widened on the host by more than the rounding of
+// r * guide_scale).  When hi - lo <= 16 the answer is lo + #{cdf[lo .. lo+15] <= r}: two dependent fetches
+// instead of six; longer brackets (dark stretches of an environment map) take the 16-ary levels.
 struct DCdfIndex {
-  int levels;        // 0: no index (short or non-monotone CDF: plain binary search); else number of levels incl. level 0
-  int top_count;     // valid entries of the top level
-  int offset[8];     // offset[k]: start of level k in light_index_pool
+  int   levels;        // 0: no index (short or non-monotone CDF: plain binary search); else number of levels incl. level 0
+  int   top_count;     // valid entries of the top level
+  int   offset[8];     // offset[k]: start of level k in light_index_pool
+  int   guide_offset, guide_buckets;
+  float guide_scale;
+  int   pad;
 };
 
 struct DScene {
@@ -109,6 +117,7 @@ struct DScene {
   const float4*    light_prims;
   const DCdfIndex* light_index;      // per light: 16-ary search index over its CDF (levels == 0: plain binary search)
   const float*     light_index_pool;
+  const int2*      light_guide;
   // implicit surfaces
   const vpt_volume*          volumes;
   const float*               voxels;

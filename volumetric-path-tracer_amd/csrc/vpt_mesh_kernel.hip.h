@@ -31,35 +31,6 @@
 #pragma once
 #include "vpt_kernels.hip.h"
 
-// Diagnostic build (-DVPT_COUNTERS): how often a wave executes each code section and with how many
-// active lanes.  Slot 2k counts wave executions, slot 2k+1 the lanes active in them.  Never in the product build.
-#ifdef VPT_COUNTERS
-__device__ unsigned long long g_vpt_cnt[64];
-VPT_DEV void vpt_cnt(int k) {
-  unsigned long long m = __builtin_amdgcn_ballot_w64(true);
-  if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
-    atomicAdd(&g_vpt_cnt[2 * k], 1ull);
-    atomicAdd(&g_vpt_cnt[2 * k + 1], (unsigned long long)__popcll(m));
-  }
-}
-#define VPT_CNT(k) vpt_cnt(k)
-// wave-level elapsed cycles per section: slot 32 + k of g_vpt_cnt (accumulated in LDS, flushed at kernel end)
-__shared__ unsigned long long s_vpt_time[16];
-VPT_DEV void vpt_time_add(int k, unsigned long long t0) {
-  unsigned long long dt = __builtin_readcyclecounter() - t0;
-  unsigned long long m  = __builtin_amdgcn_ballot_w64(true);
-  if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&s_vpt_time[k], dt);
-}
-#define VPT_T0(k) unsigned long long vpt_t0_##k = __builtin_readcyclecounter()
-#define VPT_T1(k) vpt_time_add(k, vpt_t0_##k)
-#else
-#define VPT_CNT(k)
-#define VPT_T0(k)
-#define VPT_T1(k)
-#endif
-enum { TM_NODES = 0, TM_PRIMS, TM_ENTER, TM_QUERY, TM_TRIP, TM_LIGHTS_PDF, TM_SAMPLE_LIGHTS, TM_SURFACE, TM_VOLUME, TM_GENERATE, TM_KERNEL };
-enum { CNT_NODE = 0, CNT_PRIM, CNT_ENTER, CNT_OUTER, CNT_TRIP, CNT_POP, CNT_MISS, CNT_SURFACE, CNT_VOLUME, CNT_LIGHTS, CNT_GENERATE, CNT_LEAF };
-
 // (ref, t0) stack of one lane: the first `cap` entries live in LDS (entry-major: conflict-free), deeper
 // ones in a per-launch HBM array (entry-major too: coalesced).  `cap` covers what traversals use in
 // practice; the HBM part only makes the worst case (three pending siblings on every quad level) safe.
@@ -439,6 +410,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
     if (state == ST_NEW) {
       if (sample == pr.nsamples) break;
       VPT_CNT(CNT_GENERATE);
+      VPT_T0(TM_GENERATE);
       const vpt_camera& cam = sc.cameras[pr.camera];
       float u, v;
       if (pr.preview) {
@@ -453,6 +425,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
       ray      = eval_camera(cam, mk2(u, v), lens);
       radiance = mk3(0, 0, 0), weight = mk3(1, 1, 1);
       alpha = 0, bounce = 0, in_medium = false, state = ST_MAIN;
+      VPT_T1(TM_GENERATE);
     }
 
     bool finish = false;
@@ -505,6 +478,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
         f2     l_ruv = mk2(0, 0);
         float  l_rel = 0, l_rl = 0;
         mpoint m;
+        VPT_T0(TM_MEDIUM);
         if constexpr (SH == K_VOLPATH) {
           if (in_medium) {   // cpp:586-596 — rd is drawn before rl
             float rd       = rand1f(rng);
@@ -515,6 +489,8 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
             h.distance = distance;
           }
         }
+        VPT_T1(TM_MEDIUM);
+        VPT_T0(TM_SURFACE);
         if (!in_volume) {
           const DInstance& inst = sc.instances[h.instance];
           position = eval_position(sc, inst, h.element, h.uv);
@@ -593,7 +569,10 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
               }
             }
           }
-        } else if constexpr (SH == K_VOLPATH) {   // volume event, cpp:654-673
+        }
+        VPT_T1(TM_SURFACE);
+        VPT_T0(TM_VOLUME);
+        if (in_volume) if constexpr (SH == K_VOLPATH) {   // volume event, cpp:654-673
           position = ray_point(ray, h.distance);
           radiance = radiance + weight * eval_emission(med_emission, position, outgoing);   // (sic) cpp:660
           if (rand1f(rng) < 0.5f) {
@@ -611,10 +590,12 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
           }
           scatter = 2;
         }
+        VPT_T1(TM_VOLUME);
         if constexpr (HAS_MIS) {
           VPT_T0(TM_SAMPLE_LIGHTS);
           if (want_lights) incoming = sample_lights(sc, position, l_rl, l_rel, l_ruv);
           VPT_T1(TM_SAMPLE_LIGHTS);
+          VPT_T0(TM_SCATTER_EVAL);
           if (scatter == 1) {   // cpp:626-648
             if (is_zero3(incoming)) finish = true;
             else {
@@ -633,6 +614,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
             ray        = make_ray(position, incoming);
             lp_sum = 0, lp_light = 0, advance_lights = true;
           }
+          VPT_T1(TM_SCATTER_EVAL);
         }
       }
 

@@ -11,6 +11,35 @@
 #endif
 
 
+// Diagnostic build (-DVPT_COUNTERS): how often a wave executes each code section and with how many
+// active lanes.  Slot 2k counts wave executions, slot 2k+1 the lanes active in them.  Never in the product build.
+#ifdef VPT_COUNTERS
+__device__ unsigned long long g_vpt_cnt[64];
+VPT_DEV void vpt_cnt(int k) {
+  unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+    atomicAdd(&g_vpt_cnt[2 * k], 1ull);
+    atomicAdd(&g_vpt_cnt[2 * k + 1], (unsigned long long)__popcll(m));
+  }
+}
+#define VPT_CNT(k) vpt_cnt(k)
+// wave-level elapsed cycles per section: slot 32 + k of g_vpt_cnt (accumulated in LDS, flushed at kernel end)
+__shared__ unsigned long long s_vpt_time[16];
+VPT_DEV void vpt_time_add(int k, unsigned long long t0) {
+  unsigned long long dt = __builtin_readcyclecounter() - t0;
+  unsigned long long m  = __builtin_amdgcn_ballot_w64(true);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&s_vpt_time[k], dt);
+}
+#define VPT_T0(k) unsigned long long vpt_t0_##k = __builtin_readcyclecounter()
+#define VPT_T1(k) vpt_time_add(k, vpt_t0_##k)
+#else
+#define VPT_CNT(k)
+#define VPT_T0(k)
+#define VPT_T1(k)
+#endif
+enum { TM_NODES = 0, TM_PRIMS, TM_ENTER, TM_QUERY, TM_TRIP, TM_LIGHTS_PDF, TM_SAMPLE_LIGHTS, TM_SURFACE, TM_VOLUME, TM_GENERATE, TM_KERNEL, TM_CDF, TM_SCATTER_EVAL, TM_MEDIUM };
+enum { CNT_NODE = 0, CNT_PRIM, CNT_ENTER, CNT_OUTER, CNT_TRIP, CNT_POP, CNT_MISS, CNT_SURFACE, CNT_VOLUME, CNT_LIGHTS, CNT_GENERATE, CNT_LEAF };
+
 // ------------------------------------------------------------------------------------------------
 // per-lane traversal stack in LDS: entry e of lane t lives at lds[e * VPT_BLOCK + t], so the 64
 // lanes of a wave touch 64 consecutive dwords (conflict-free ds_read_b32 / ds_write_b32).
@@ -443,6 +472,18 @@ VPT_DEV int sample_light_cdf(const DScene& sc, int light_id, float r) {
   if (ix.levels == 0) return sample_discrete(cdf, n, r);
   float back = cdf[n - 1];
   r = clampf(r * back, 0.0f, back - 0.00001f);
+  if (ix.guide_buckets > 0) {   // bracket from the guide table; short brackets are resolved with one 16-wide fetch
+    int  b  = (int)(r * ix.guide_scale);
+    int2 lh = sc.light_guide[ix.guide_offset + (b < ix.guide_buckets ? b : ix.guide_buckets - 1)];
+    if (__builtin_amdgcn_ballot_w64(lh.y - lh.x > 16) == 0) {
+      const float* g = sc.light_index_pool + ix.offset[0] + lh.x;   // level 0 = the CDF, padded with +inf
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) cnt += (int)!(r < g[i]);
+      int found = lh.x + cnt;
+      return found < n ? found : n - 1;
+    }
+  }
   int idx = count_not_above(sc.light_index_pool + ix.offset[ix.levels - 1], r);
   if (idx >= ix.top_count) return n - 1;   // no element above r: upper_bound == n, clamped
   // the group found at one level holds an entry > r (its maximum is the entry just passed), so every level
@@ -972,7 +1013,9 @@ VPT_DEV f3 sample_lights(const DScene& sc, f3 position, float rl, float rel, f2 
   float4        r6 = rec[6], r7 = rec[7];
   int           kind = __float_as_int(r7.w) & 255;
   // the one CDF search of this call: emissive mesh -> element, textured environment -> texel
+  VPT_T0(TM_CDF);
   int pick = (kind == VPT_LIGHT_SMALL_MESH || kind == VPT_LIGHT_LARGE_MESH || kind == VPT_LIGHT_ENV_TEX) ? sample_light_cdf(sc, light_id, rel) : 0;
+  VPT_T1(TM_CDF);
   if (kind == VPT_LIGHT_SMALL_MESH) {
     // eval_position (yocto_scene.cpp:279-303) from the light's own copy of its <= 4 primitives
     const float4* prims = sc.light_prims + 20 * (long long)light_id;

@@ -20,7 +20,7 @@ for k, n in enumerate(names):
     w, l = out[2 * k], out[2 * k + 1]
     if w: print(f"{n:20s} {w / slots:22.2f} {l / nsamp:18.2f} {l / w:10.1f}")
 
-tn = ['A node loops', 'B prim phases', 'C instance entry', 'whole query', 'trip', 'lights pdf loop + MIS', 'sample_lights', 'surface event', 'volume event', 'generate', 'kernel', 'light CDF search', 'scatter eval (bsdf/phase)', 'medium distance sampling']
+tn = ['A node loops', 'B prim phases', 'C instance entry', 'whole query', 'trip', 'lights pdf loop + MIS', 'sample_lights', 'surface event', 'volume event', 'generate', 'kernel', 'light CDF search', 'scatter eval (bsdf/phase)', 'medium distance sampling', 'surface: position+normal+material', 'surface: delta lobe']
 tot = out[32 + 10]
 print()
 for k, n in enumerate(tn):

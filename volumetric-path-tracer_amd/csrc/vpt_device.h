@@ -67,7 +67,7 @@ struct DCdfIndex {
 struct DScene {
   // counts
   int num_cameras, num_instances, num_shapes, num_materials, num_textures, num_environments;
-  int num_volumes, num_vol_instances, num_sdfs, num_lights, num_scene_nodes, pad0;
+  int num_volumes, num_vol_instances, num_sdfs, num_lights, num_scene_nodes, num_scene_prims;
   // bvh
   const float4* scene_nodes;   // 2 per node
   const int*    scene_prims;

@@ -134,6 +134,9 @@ VPT_DEV bool has_zero(f3 d) { return d.x == 0 || d.y == 0 || d.z == 0; }
 //      reference's shape-level loop does first, yocto_bvh.cpp:728-733); instances that miss it are
 //      skipped without ever leaving world space.
 #define VPT_NONE (-2147483647 - 1)
+#ifndef VPT_HOIST_MAX
+#define VPT_HOIST_MAX 16   // scenes with at most this many instances test all root boxes at the start of a query
+#endif
 template <class STK>
 VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const STK& stk) {
   hit_t r;
@@ -170,11 +173,14 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
   // is {I, -o} only needs co: 1*d + 0*d' + 0*d'' == d bit for bit when no component is zero, and
   // ((1*o.x + 0*o.y) + 0*o.z) + t == o.x + t.  co itself is restored once, when the leaf is exhausted.
   // Returns the lane's next reference.
+  unsigned reach = 0xffffffffu;   // bit s clear: the instance in slot s cannot pass its root-box test whatever tmax is (below)
   auto enter_pending = [&]() {
     while (pend & 15) {
-      VPT_CNT(CNT_ENTER);
-      const float4* e = sc.scene_enter + 6 * (long long)(pend >> 4);
+      int slot = pend >> 4;
       pend += 15;   // first slot + 1, count - 1
+      if (!((reach >> (slot & 31)) & 1)) continue;
+      VPT_CNT(CNT_ENTER);
+      const float4* e = sc.scene_enter + 6 * (long long)slot;
       float4 e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5];
       bool   general = !__float_as_int(e5.z) || wslow;
       if (general) {
@@ -203,6 +209,31 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
     if (sc.num_scene_nodes && box_test(slow, mk3(sc.scene_root_lo_x, sc.scene_root_lo_y, sc.scene_root_lo_z),
                                   mk3(sc.scene_root_hi_x, sc.scene_root_hi_y, sc.scene_root_hi_z), co, cinv, tmin, tmax, t0))
       cur = sc.scene_root_ref;
+    // Small scenes: every lane tests the root boxes of ALL instances now, in lockstep (the slot index is
+    // wave-uniform: scalar record loads, no divergence), with tmax = inf.  A box missed with tmax = inf is missed
+    // with any tmax (t1 = min(far, tmax) * k only shrinks), so phase C skips those instances without fetching
+    // their records; the others are tested again there against the current tmax, as the reference does.
+    // Entering instances one lane at a time is the most divergent part of a query (13 of 64 lanes active).
+    if (sc.num_scene_prims <= VPT_HOIST_MAX && cur != VPT_NONE) {
+      bool any_slow = __builtin_amdgcn_ballot_w64(wslow) != 0;
+      reach = 0;
+      for (int s = 0; s < sc.num_scene_prims; s++) {
+        const float4* e = sc.scene_enter + 6 * s;
+        float4 e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5];
+        f3   lo, linv;
+        bool lslow;
+        if (!__float_as_int(e5.z) || any_slow) {
+          frame inv = unpack_frame(e[0], e[1], e2);
+          f3    ld  = transform_vector(inv, wd);
+          lo = transform_point(inv, wo), linv = rcp3_exact(ld), lslow = has_zero(ld);
+        } else {
+          lo = mk3(wo.x + e2.y, wo.y + e2.z, wo.z + e2.w), linv = winv, lslow = false;
+        }
+        float t0;
+        if (__float_as_int(e5.w) && box_test(lslow, mk3(e3.x, e3.y, e3.z), mk3(e3.w, e4.x, e4.y), lo, linv, tmin, VPT_FLT_MAX, t0))
+          reach |= 1u << s;
+      }
+    }
   } else {   // single-instance query (yocto_bvh.cpp:874-881)
     pend = (sc.slot_of_instance[only_instance] << 4) | 1;
     cur  = enter_pending();
@@ -493,9 +524,11 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
         VPT_T0(TM_SURFACE);
         if (!in_volume) {
           const DInstance& inst = sc.instances[h.instance];
+          VPT_T0(TM_SURF_GEOM);
           position = eval_position(sc, inst, h.element, h.uv);
           normal   = eval_shading_normal(sc, inst, h.element, h.uv, outgoing);
           m        = eval_material(sc, inst, h.element, h.uv);
+          VPT_T1(TM_SURF_GEOM);
           if (m.opacity < 1 && rand1f(rng) >= m.opacity) {
             ray = make_ray(position + ray.d * 1e-2f, ray.d);   // bounce -= 1; continue
           } else {
@@ -552,6 +585,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
                 }
                 scatter = 1;
               } else {
+                VPT_T0(TM_SURF_DELTA);
                 float rnl = rand1f(rng);
                 incoming  = sample_delta(m, normal, outgoing, rnl);
                 weight    = weight * (eval_delta(m, normal, outgoing, incoming) / sample_delta_pdf(m, normal, outgoing, incoming));
@@ -566,6 +600,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
                 ray = make_ray(position, incoming);
                 if (!survive(weight, bounce, rng)) finish = true;
                 bounce++;
+                VPT_T1(TM_SURF_DELTA);
               }
             }
           }

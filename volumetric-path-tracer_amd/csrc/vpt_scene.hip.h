@@ -37,7 +37,7 @@ VPT_DEV void vpt_time_add(int k, unsigned long long t0) {
 #define VPT_T0(k)
 #define VPT_T1(k)
 #endif
-enum { TM_NODES = 0, TM_PRIMS, TM_ENTER, TM_QUERY, TM_TRIP, TM_LIGHTS_PDF, TM_SAMPLE_LIGHTS, TM_SURFACE, TM_VOLUME, TM_GENERATE, TM_KERNEL, TM_CDF, TM_SCATTER_EVAL, TM_MEDIUM };
+enum { TM_NODES = 0, TM_PRIMS, TM_ENTER, TM_QUERY, TM_TRIP, TM_LIGHTS_PDF, TM_SAMPLE_LIGHTS, TM_SURFACE, TM_VOLUME, TM_GENERATE, TM_KERNEL, TM_CDF, TM_SCATTER_EVAL, TM_MEDIUM, TM_SURF_GEOM, TM_SURF_DELTA };
 enum { CNT_NODE = 0, CNT_PRIM, CNT_ENTER, CNT_OUTER, CNT_TRIP, CNT_POP, CNT_MISS, CNT_SURFACE, CNT_VOLUME, CNT_LIGHTS, CNT_GENERATE, CNT_LEAF };
 
 // ------------------------------------------------------------------------------------------------

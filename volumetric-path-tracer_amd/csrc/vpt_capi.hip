@@ -436,8 +436,9 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   if ((size_t)s->stack_cap * VPT_BLOCK * sizeof(int) > 64 * 1024)
     return fail(VPT_ERR_UNSUPPORTED, "BVH depth %d needs a %d-entry traversal stack; the LDS stack holds 64", need, s->stack_cap);
   // quad-node traversal: worst case = three pending siblings per quad level of the scene BVH plus of the
-  // deepest shape BVH.  24 entries per lane keep three 256-lane workgroups on a CU (3 x 48 KB of 160 KB);
-  // whatever the worst case needs beyond that lives in HBM (lane_stack2).
+  // deepest shape BVH, plus one free entry above the top (the branch-free push stores rejected candidates
+  // there).  24 entries per lane = 12 KB per wave keep twelve waves on a CU (144 of 160 KB); whatever the
+  // worst case needs beyond that lives in HBM (lane_stack2<true>).
   int need4 = scene_need4 + max_shape_need4 + 1;
   s->stack_lds4   = need4 < 8 ? 8 : need4 > 24 ? 24 : ((need4 + 3) & ~3);
   s->stack_spill4 = need4 > s->stack_lds4 ? need4 - s->stack_lds4 : 0;

@@ -127,3 +127,30 @@ VPT_DEV unsigned int advance_rng(rng_t& rng) {
   return (xs >> rot) | (xs << ((~rot + 1u) & 31));
 }
 VPT_DEV float rand1f(rng_t& rng) { return __uint_as_float((advance_rng(rng) >> 9) | 0x3f800000u) - 1.0f; }
+
+// ------------------------------------------------------------------------------------------------
+// Hardware min/max (no sNaN quieting moves around them: the operands below are never NaN)
+VPT_DEV float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+VPT_DEV float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+VPT_DEV float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+VPT_DEV float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// 1/x bit-identical to the IEEE quotient 1.0f/x.  v_rcp_f32 followed by one Newton step is correctly
+// rounded for EVERY float whose biased exponent is 1..250 (2^-126 <= |x| < 2^124): checked exhaustively on
+// gfx950 by vpt_selftest_reciprocal() (tests/test_gpu_parity.py).  Other inputs (0, denormals, huge, inf,
+// NaN) take the division; the choice is made per wave so that only one of the two sequences is executed.
+VPT_DEV float rcp_newton(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+VPT_DEV bool rcp_in_range(float lo_abs, float hi_abs) { return lo_abs >= 0x1p-126f && hi_abs < 0x1p124f; }
+VPT_DEV float rcp_exact(float x) {
+  float a = __builtin_fabsf(x);
+  if (__builtin_amdgcn_ballot_w64(!rcp_in_range(a, a)) == 0) return rcp_newton(x);
+  return 1 / x;
+}
+VPT_DEV f3 rcp3_exact(f3 d) {
+  float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+  if (__builtin_amdgcn_ballot_w64(!rcp_in_range(hw_min3(ax, ay, az), hw_max3(ax, ay, az))) == 0)
+    return mk3(rcp_newton(d.x), rcp_newton(d.y), rcp_newton(d.z));
+  return mk3(1 / d.x, 1 / d.y, 1 / d.z);
+}

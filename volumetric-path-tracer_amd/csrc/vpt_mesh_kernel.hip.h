@@ -51,6 +51,10 @@ struct lane_stack2 {
     else deep[(sp - cap) * lanes] = make_int2(ref, __float_as_int(t0));
     sp++;
   }
+  VPT_DEV void put(int pos, int ref, float t0) const {   // LDS part only
+    base[(2 * pos) * VPT_BLOCK] = ref, base[(2 * pos + 1) * VPT_BLOCK] = __float_as_int(t0);
+  }
+  static constexpr bool spills = SPILL;
   VPT_DEV void pop(int& sp, int& ref, float& t0) const {
     sp--;
     if (!SPILL || sp < cap) ref = base[(2 * sp) * VPT_BLOCK], t0 = __int_as_float(base[(2 * sp + 1) * VPT_BLOCK]);
@@ -81,31 +85,6 @@ VPT_DEV bool box_pass(f3 bmin, f3 bmax, f3 o, f3 dinv, float tmin, float tmax, f
 }
 VPT_DEV int sign_bits(f3 dinv) { return (dinv.x < 0 ? 1 : 0) | (dinv.y < 0 ? 2 : 0) | (dinv.z < 0 ? 4 : 0); }
 
-// Hardware min/max (no sNaN quieting moves around them: the operands below are never NaN)
-VPT_DEV float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-VPT_DEV float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-VPT_DEV float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-VPT_DEV float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-// 1/x bit-identical to the IEEE quotient 1.0f/x.  v_rcp_f32 followed by one Newton step is correctly
-// rounded for EVERY float whose biased exponent is 1..250 (2^-126 <= |x| < 2^124): checked exhaustively on
-// gfx950 by vpt_selftest_reciprocal() (tests/test_gpu_parity.py).  Other inputs (0, denormals, huge, inf,
-// NaN) take the division; the choice is made per wave so that only one of the two sequences is executed.
-VPT_DEV float rcp_newton(float x) {
-  float r = __builtin_amdgcn_rcpf(x);
-  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
-}
-VPT_DEV bool rcp_in_range(float lo_abs, float hi_abs) { return lo_abs >= 0x1p-126f && hi_abs < 0x1p124f; }
-VPT_DEV float rcp_exact(float x) {
-  float a = __builtin_fabsf(x);
-  if (__builtin_amdgcn_ballot_w64(!rcp_in_range(a, a)) == 0) return rcp_newton(x);
-  return 1 / x;
-}
-VPT_DEV f3 rcp3_exact(f3 d) {
-  float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
-  if (__builtin_amdgcn_ballot_w64(!rcp_in_range(hw_min3(ax, ay, az), hw_max3(ax, ay, az))) == 0)
-    return mk3(rcp_newton(d.x), rcp_newton(d.y), rcp_newton(d.z));
-  return mk3(1 / d.x, 1 / d.y, 1 / d.z);
-}
 // same test with 3-operand min/max; only valid when no product can be NaN (no zero in the direction):
 // min/max of non-NaN values do not depend on how they are associated, so the result is the reference's
 VPT_DEV bool box_pass_fast(f3 bmin, f3 bmax, f3 o, f3 dinv, float tmin, float tmax, float& t0) {
@@ -274,19 +253,33 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
       float w0 = gn ? u0 : s0, w1 = gn ? u1 : s1, w2 = gn ? s0 : u0, w3 = gn ? s1 : u1;
       // push the later-visited ones (last first); the first-visited one is taken directly: it would be
       // popped next with the same tmax, so its pop test is a tautology
-      int   next = v3;
-      float nt   = w3;
-      if (v2 != VPT_NONE) {
-        if (next != VPT_NONE) stk.push(sp, next, nt);
-        next = v2, nt = w2;
-      }
-      if (v1 != VPT_NONE) {
-        if (next != VPT_NONE) stk.push(sp, next, nt);
-        next = v1, nt = w1;
-      }
-      if (v0 != VPT_NONE) {
-        if (next != VPT_NONE) stk.push(sp, next, nt);
-        next = v0;
+      int next;
+      if constexpr (!STK::spills) {
+        // branch-free: every candidate is stored; one that is not pushed lands on the free entry above the new
+        // top (the host sizes the LDS part one entry larger than the worst case)
+        bool f0 = v0 != VPT_NONE, f1 = v1 != VPT_NONE, f2 = v2 != VPT_NONE, f3 = v3 != VPT_NONE;
+        bool q3 = f3 && (f2 || f1 || f0), q2 = f2 && (f1 || f0), q1 = f1 && f0;
+        int  top = sp + (int)q3 + (int)q2 + (int)q1;
+        stk.put(q3 ? sp : top, v3, w3);
+        stk.put(q2 ? sp + (int)q3 : top, v2, w2);
+        stk.put(q1 ? sp + (int)q3 + (int)q2 : top, v1, w1);
+        sp   = top;
+        next = f0 ? v0 : f1 ? v1 : f2 ? v2 : v3;
+      } else {
+        float nt = w3;
+        next     = v3;
+        if (v2 != VPT_NONE) {
+          if (next != VPT_NONE) stk.push(sp, next, nt);
+          next = v2, nt = w2;
+        }
+        if (v1 != VPT_NONE) {
+          if (next != VPT_NONE) stk.push(sp, next, nt);
+          next = v1, nt = w1;
+        }
+        if (v0 != VPT_NONE) {
+          if (next != VPT_NONE) stk.push(sp, next, nt);
+          next = v0;
+        }
       }
       cur = next != VPT_NONE ? next : pop_valid();
     }

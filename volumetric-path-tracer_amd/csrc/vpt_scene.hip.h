@@ -69,7 +69,7 @@ VPT_DEV bool intersect_triangle(f3 ro, f3 rd, float tmin, float tmax, f3 p0, f3 
   f3    pvec  = cross(rd, edge2);
   float det   = dot(edge1, pvec);
   if (det == 0) return false;
-  float inv_det = 1.0f / det;
+  float inv_det = rcp_exact(det);   // == 1.0f / det bit for bit (vpt_math.hip.h)
   f3    tvec    = ro - p0;
   float u       = dot(tvec, pvec) * inv_det;
   if (u < 0 || u > 1) return false;

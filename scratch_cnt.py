@@ -10,7 +10,12 @@ st = scene.make_state(p)
 spp = 16
 out = (ctypes.c_ulonglong * 64)()
 lib.vpt_debug_counts(out, 1)
+import time
+dev.pathtrace_samples(st, p, 1)
+lib.vpt_debug_counts(out, 1)
+t0 = time.perf_counter()
 dev.pathtrace_samples(st, p, spp)
+dt = time.perf_counter() - t0
 lib.vpt_debug_counts(out, 0)
 names = ['node step', 'prim test', 'instance entry', 'outer iteration', 'trip (query)', 'pop', 'miss', 'surface', 'volume', 'lights', 'generate', 'leaf']
 nsamp = st.width * st.height * spp
@@ -25,3 +30,5 @@ tot = out[32 + 10]
 print()
 for k, n in enumerate(tn):
     if out[32 + k]: print(f"{n:24s} {100.0 * out[32 + k] / tot:6.2f} % of wave time")
+
+print(f"host time of the launch {dt*1e3:.1f} ms; sum of wave times {tot} ticks; if ticks are 10 ns: mean waves in flight {tot*1e-8/dt:.0f} of {256*4*3}")

@@ -441,6 +441,10 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   // worst case needs beyond that lives in HBM (lane_stack2<true>).
   int need4 = scene_need4 + max_shape_need4 + 1;
   s->stack_lds4   = need4 < 8 ? 8 : need4 > 24 ? 24 : ((need4 + 3) & ~3);
+  if (const char* e = getenv("VPT_STACK_LDS")) {   // tuning experiments: force a smaller LDS part (the rest spills to HBM)
+    int v = atoi(e);
+    if (v >= 4 && v < s->stack_lds4) s->stack_lds4 = v;
+  }
   s->stack_spill4 = need4 > s->stack_lds4 ? need4 - s->stack_lds4 : 0;
   if (getenv("VPT_DEBUG"))
     fprintf(stderr, "[vpt] binary depth scene %d shape %d; quad stack need scene %d + shape %d + 1 -> %d in LDS + %d in HBM\n",

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "vpt_stream_kernels.hip.h"
+#include <rocprim/rocprim.hpp>
 
 // light_prims of the single-leaf mesh lights (vpt_device.h): one thread per (light, primitive of the leaf)
 __global__ void vpt_light_setup_kernel(DScene sc, float4* out) {
@@ -167,6 +168,14 @@ struct vpt_scene {
   int                stack_lds4 = 8, stack_spill4 = 0;   // quad-node traversal: (ref, t0) entries in LDS / in HBM
   void*              spill = nullptr;
   long long          spill_lanes = 0;
+  // launch schedule of the mesh kernel (sched_cfg): per-wave cost of the last launch, waves by descending cost
+  unsigned *d_cost = nullptr, *d_cost_sorted = nullptr;
+  int *     d_order = nullptr, *d_iota = nullptr;
+  void*     sort_temp = nullptr;
+  size_t    sort_temp_bytes = 0;
+  long long sched_waves = 0;       // waves the buffers are sized for
+  bool      order_valid = false;   // d_order describes the layout of sched_key
+  long long sched_key[6] = {0, 0, 0, 0, 0, 0};
   // staging for the host-state entry point vpt_render()
   void *s_image = nullptr, *s_hits = nullptr, *s_rng = nullptr;   // tile-major state
   void *r_image = nullptr, *r_hits = nullptr, *r_rng = nullptr;   // row-major mirror
@@ -348,6 +357,8 @@ void vpt_scene_destroy(vpt_scene* s) {
     if (p) (void)hipFree(p);
   for (void* p : s->path_allocs) (void)hipFree(p);
   if (s->spill) (void)hipFree(s->spill);
+  for (void* p : {(void*)s->d_cost, (void*)s->d_cost_sorted, (void*)s->d_order, (void*)s->d_iota, s->sort_temp})
+    if (p) (void)hipFree(p);
   if (s->host_counts) (void)hipHostFree(s->host_counts);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -721,6 +732,37 @@ static int stack_config(vpt_scene* s, long long lanes, stack_cfg& cfg) {
   return VPT_OK;
 }
 
+// Buffers of the launch schedule for `waves` waves; a change of layout / camera / shader forgets the measured costs.
+static int sched_prepare(vpt_scene* s, long long waves, const long long key[6], hipStream_t st) {
+  if (waves > s->sched_waves) {
+    for (void** p : {(void**)&s->d_cost, (void**)&s->d_cost_sorted, (void**)&s->d_order, (void**)&s->d_iota, &s->sort_temp})
+      if (*p) (void)hipFree(*p), *p = nullptr;
+    s->sched_waves = 0, s->order_valid = false;
+    HIP_TRY(hipMalloc((void**)&s->d_cost, waves * 4));
+    HIP_TRY(hipMalloc((void**)&s->d_cost_sorted, waves * 4));
+    HIP_TRY(hipMalloc((void**)&s->d_order, waves * 4));
+    HIP_TRY(hipMalloc((void**)&s->d_iota, waves * 4));
+    HIP_TRY(hipMemset(s->d_cost, 0, waves * 4));   // waves that own no pixel never write theirs
+    std::vector<int> iota((size_t)waves);
+    for (long long i = 0; i < waves; i++) iota[(size_t)i] = (int)i;
+    HIP_TRY(hipMemcpy(s->d_iota, iota.data(), waves * 4, hipMemcpyHostToDevice));
+    size_t bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs_desc((void*)nullptr, bytes, s->d_cost, s->d_cost_sorted, s->d_iota, s->d_order, (size_t)waves));
+    HIP_TRY(hipMalloc(&s->sort_temp, bytes ? bytes : 16));
+    s->sort_temp_bytes = bytes, s->sched_waves = waves;
+  }
+  if (memcmp(key, s->sched_key, sizeof(s->sched_key)) != 0) s->order_valid = false, memcpy(s->sched_key, key, sizeof(s->sched_key));
+  (void)st;
+  return VPT_OK;
+}
+// order[] for the next launch from the costs the launch just enqueued on `st` will have written
+static int sched_update(vpt_scene* s, long long waves, hipStream_t st) {
+  size_t bytes = s->sort_temp_bytes;
+  HIP_TRY(rocprim::radix_sort_pairs_desc(s->sort_temp, bytes, s->d_cost, s->d_cost_sorted, s->d_iota, s->d_order, (size_t)waves, 0, 32, st));
+  s->order_valid = true;
+  return VPT_OK;
+}
+
 // The streaming form of K1: k_begin, then (k_trace, k_shade) pairs until every queue is empty.
 // Queue sizes only shrink, so the grid follows the last count read back (every 16 iterations).
 template <int K>
@@ -790,10 +832,20 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
   do {                                                                                                          \
     if (use_stream_pipeline()) {                                                                                \
       if (int rc_ = render_stream<K>(s, pr, img, hit, rng, st)) return rc_;                                     \
-    } else if (stack.spill) {                                                                                   \
-      hipLaunchKernelGGL((vpt_mesh_kernel<K, true>), grid, block, lds2, st, s->d, pr, img, hit, rng, stack);    \
     } else {                                                                                                    \
-      hipLaunchKernelGGL((vpt_mesh_kernel<K, false>), grid, block, lds2, st, s->d, pr, img, hit, rng, stack);   \
+      /* without measured costs, a one-sample pilot launch (same arithmetic: batching is exact) provides them */ \
+      long long key_[6] = {pr.nslots, pr.width, pr.height, params->shader, params->camera, params->bounces};      \
+      if (int rc_ = sched_prepare(s, grid.x, key_, st)) return rc_;                                             \
+      int parts_[2] = {(!s->order_valid && pr.nsamples >= 16) ? 1 : pr.nsamples, 0};                            \
+      parts_[1] = pr.nsamples - parts_[0];                                                                       \
+      for (int part_ = 0; part_ < 2 && parts_[part_] > 0; part_++) {                                            \
+        DParams   prp_ = pr;                                                                                     \
+        prp_.nsamples  = parts_[part_];                                                                          \
+        sched_cfg sch_ = {s->order_valid ? s->d_order : nullptr, s->d_cost};                                     \
+        if (stack.spill) hipLaunchKernelGGL((vpt_mesh_kernel<K, true>), grid, block, lds2, st, s->d, prp_, img, hit, rng, stack, sch_);  \
+        else hipLaunchKernelGGL((vpt_mesh_kernel<K, false>), grid, block, lds2, st, s->d, prp_, img, hit, rng, stack, sch_);             \
+        if (int rc_ = sched_update(s, grid.x, st)) return rc_;                                                  \
+      }                                                                                                         \
     }                                                                                                           \
   } while (0)
   switch (params->shader) {

@@ -34,6 +34,15 @@
 // (ref, t0) stack of one lane: the first `cap` entries live in LDS (entry-major: conflict-free), deeper
 // ones in a per-launch HBM array (entry-major too: coalesced).  `cap` covers what traversals use in
 // practice; the HBM part only makes the worst case (three pending siblings on every quad level) safe.
+// Launch schedule.  A wave's 64 pixels run all their samples in sequence, so a wave's duration is fixed by its
+// tile's content and varies 15x across 03_volume; in tile order the launch ends with a third of the GPU idle
+// behind a few long waves.  Every wave records its duration; the next launch on the same layout starts the
+// waves longest first (order[] = wave indices by descending cost: LPT list scheduling).  Results do not depend
+// on the order (pixels are independent), only the makespan does.
+struct sched_cfg {
+  const int* order;   // blockIdx.x -> wave index, or null: identity
+  unsigned*  cost;    // per wave: duration of this launch in 100 MHz ticks, or null
+};
 struct stack_cfg {
   int        cap;      // entries per lane in LDS
   int        spill;    // entries per lane in HBM
@@ -397,14 +406,16 @@ enum { ST_NEW = 0, ST_MAIN = 1, ST_LPDF = 2 };
 
 template <int SH, bool SPILL>
 __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel(DScene sc, DParams pr,
-    float4* __restrict__ image, int* __restrict__ hits, ulonglong2* __restrict__ rngs, stack_cfg stack) {
+    float4* __restrict__ image, int* __restrict__ hits, ulonglong2* __restrict__ rngs, stack_cfg stack, sched_cfg sched) {
   extern __shared__ int lds_stack[];
   const lane_stack2<SPILL> stk = make_lane_stack<SPILL>(lds_stack, stack);
+  const unsigned long long wave_start = wall_clock64();
+  const int wave = sched.order ? sched.order[blockIdx.x] : (int)blockIdx.x;
 #ifdef VPT_COUNTERS
   if (threadIdx.x < 16) s_vpt_time[threadIdx.x] = 0;
 #endif
 
-  int slot = blockIdx.x * VPT_BLOCK + threadIdx.x;
+  int slot = wave * VPT_BLOCK + threadIdx.x;
   int px = 0, py = 0;
   if (slot >= pr.nslots || !slot_to_pixel(pr, slot, px, py)) return;   // padding lanes own no pixel
 
@@ -694,4 +705,8 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
   ulonglong2 r_out;
   r_out.x = rng.state, r_out.y = rng.inc;
   rngs[slot] = r_out;
+  if (sched.cost && threadIdx.x == 0) {   // lane 0 (the tile's corner pixel) exists whenever the wave owns a pixel
+    unsigned long long dt = wall_clock64() - wave_start;
+    sched.cost[wave] = dt < 0xffffffffull ? (unsigned)dt : 0xffffffffu;
+  }
 }

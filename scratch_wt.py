@@ -7,8 +7,8 @@ scene = vpt.HostScene('tests/golden/scenes/03_volume/volume.json')
 dev = vpt.DeviceScene(scene, 0)
 p = vpt.PathtraceParams(resolution=1280, samples=1 << 30, shader='volpathtrace', bounces=64)
 st = scene.make_state(p)
-dev.pathtrace_samples(st, p, 1)
 spp = 64
+dev.pathtrace_samples(st, p, spp)
 dev.pathtrace_samples(st, p, spp)
 nw = (st.width * st.height + 63) // 64   # upper bound; tile-major layout pads
 nw = min(nw + 64, 65536)

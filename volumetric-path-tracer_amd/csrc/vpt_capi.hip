@@ -175,7 +175,7 @@ struct vpt_scene {
   size_t    sort_temp_bytes = 0;
   long long sched_waves = 0;       // waves the buffers are sized for
   bool      order_valid = false;   // d_order describes the layout of sched_key
-  long long sched_key[6] = {0, 0, 0, 0, 0, 0};
+  long long sched_key[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   // staging for the host-state entry point vpt_render()
   void *s_image = nullptr, *s_hits = nullptr, *s_rng = nullptr;   // tile-major state
   void *r_image = nullptr, *r_hits = nullptr, *r_rng = nullptr;   // row-major mirror
@@ -733,7 +733,7 @@ static int stack_config(vpt_scene* s, long long lanes, stack_cfg& cfg) {
 }
 
 // Buffers of the launch schedule for `waves` waves; a change of layout / camera / shader forgets the measured costs.
-static int sched_prepare(vpt_scene* s, long long waves, const long long key[6], hipStream_t st) {
+static int sched_prepare(vpt_scene* s, long long waves, const long long key[10], hipStream_t st) {
   if (waves > s->sched_waves) {
     for (void** p : {(void**)&s->d_cost, (void**)&s->d_cost_sorted, (void**)&s->d_order, (void**)&s->d_iota, &s->sort_temp})
       if (*p) (void)hipFree(*p), *p = nullptr;
@@ -834,7 +834,8 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
       if (int rc_ = render_stream<K>(s, pr, img, hit, rng, st)) return rc_;                                     \
     } else {                                                                                                    \
       /* without measured costs, a one-sample pilot launch (same arithmetic: batching is exact) provides them */ \
-      long long key_[6] = {pr.nslots, pr.width, pr.height, params->shader, params->camera, params->bounces};      \
+      long long key_[10] = {pr.nslots, pr.width, pr.height, params->shader, params->camera, params->bounces,      \
+                            pr.rank, pr.nranks, pr.tile_w, pr.tile_h};                                            \
       if (int rc_ = sched_prepare(s, grid.x, key_, st)) return rc_;                                             \
       int parts_[2] = {(!s->order_valid && pr.nsamples >= 16) ? 1 : pr.nsamples, 0};                            \
       parts_[1] = pr.nsamples - parts_[0];                                                                       \
@@ -842,8 +843,11 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
         DParams   prp_ = pr;                                                                                     \
         prp_.nsamples  = parts_[part_];                                                                          \
         sched_cfg sch_ = {s->order_valid ? s->d_order : nullptr, s->d_cost};                                     \
-        if (stack.spill) hipLaunchKernelGGL((vpt_mesh_kernel<K, true>), grid, block, lds2, st, s->d, prp_, img, hit, rng, stack, sch_);  \
-        else hipLaunchKernelGGL((vpt_mesh_kernel<K, false>), grid, block, lds2, st, s->d, prp_, img, hit, rng, stack, sch_);             \
+        bool pilot_ = parts_[1] > 0 && part_ == 0;                                                               \
+        if (pilot_ && stack.spill) hipLaunchKernelGGL((vpt_mesh_pilot_kernel<K, true>), grid, block, lds2, st, s->d, prp_, img, hit, rng, stack, sch_);   \
+        else if (pilot_) hipLaunchKernelGGL((vpt_mesh_pilot_kernel<K, false>), grid, block, lds2, st, s->d, prp_, img, hit, rng, stack, sch_);            \
+        else if (stack.spill) hipLaunchKernelGGL((vpt_mesh_kernel<K, true>), grid, block, lds2, st, s->d, prp_, img, hit, rng, stack, sch_);              \
+        else hipLaunchKernelGGL((vpt_mesh_kernel<K, false>), grid, block, lds2, st, s->d, prp_, img, hit, rng, stack, sch_);                              \
         if (int rc_ = sched_update(s, grid.x, st)) return rc_;                                                  \
       }                                                                                                         \
     }                                                                                                           \
@@ -929,6 +933,13 @@ int vpt_selftest_reciprocal(int device, unsigned long long* mismatches, unsigned
   *mismatches = h[0], *fallbacks = h[1];
   return rc;
 }
+
+#ifdef VPT_WAVE_TIMES
+int vpt_debug_wave_times(unsigned long long* out, int nwaves) {
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vpt_wave_times), sizeof(unsigned long long) * 2 * (size_t)nwaves));
+  return VPT_OK;
+}
+#endif
 
 #ifdef VPT_COUNTERS
 // diagnostic build only: read (and optionally clear) the section counters of vpt_mesh_kernel.hip.h

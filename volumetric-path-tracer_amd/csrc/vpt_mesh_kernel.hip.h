@@ -404,9 +404,14 @@ enum { ST_NEW = 0, ST_MAIN = 1, ST_LPDF = 2 };
 #define VPT_WAVES_PER_SIMD 2
 #endif
 
+#ifdef VPT_WAVE_TIMES
+// diagnostic build: start / end of every wave on the 100 MHz wall clock, to draw the launch's occupancy timeline
+__device__ unsigned long long g_vpt_wave_times[2 * 65536];
+#endif
+
 template <int SH, bool SPILL>
-__global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel(DScene sc, DParams pr,
-    float4* __restrict__ image, int* __restrict__ hits, ulonglong2* __restrict__ rngs, stack_cfg stack, sched_cfg sched) {
+VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __restrict__ image, int* __restrict__ hits,
+    ulonglong2* __restrict__ rngs, const stack_cfg& stack, const sched_cfg& sched) {
   extern __shared__ int lds_stack[];
   const lane_stack2<SPILL> stk = make_lane_stack<SPILL>(lds_stack, stack);
   const unsigned long long wave_start = wall_clock64();
@@ -708,5 +713,21 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel
   if (sched.cost && threadIdx.x == 0) {   // lane 0 (the tile's corner pixel) exists whenever the wave owns a pixel
     unsigned long long dt = wall_clock64() - wave_start;
     sched.cost[wave] = dt < 0xffffffffull ? (unsigned)dt : 0xffffffffu;
+#ifdef VPT_WAVE_TIMES
+    if (wave < 65536) g_vpt_wave_times[2 * wave] = wave_start, g_vpt_wave_times[2 * wave + 1] = wave_start + dt;
+#endif
   }
+}
+
+template <int SH, bool SPILL>
+__global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel(DScene sc, DParams pr,
+    float4* __restrict__ image, int* __restrict__ hits, ulonglong2* __restrict__ rngs, stack_cfg stack, sched_cfg sched) {
+  mesh_kernel_body<SH, SPILL>(sc, pr, image, hits, rngs, stack, sched);
+}
+// The same kernel under another name: the one-sample launch that measures per-wave costs when none are
+// known yet (vpt_capi.hip).  Kept apart so that profiles of vpt_mesh_kernel only hold full launches.
+template <int SH, bool SPILL>
+__global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_pilot_kernel(DScene sc, DParams pr,
+    float4* __restrict__ image, int* __restrict__ hits, ulonglong2* __restrict__ rngs, stack_cfg stack, sched_cfg sched) {
+  mesh_kernel_body<SH, SPILL>(sc, pr, image, hits, rngs, stack, sched);
 }

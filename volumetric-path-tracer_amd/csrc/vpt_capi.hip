@@ -827,7 +827,16 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
   auto   hit = (int*)d_hits;
   auto   rng = (ulonglong2*)d_rng;
   HIP_TRY(hipEventRecord(s->ev0, st));
-#define LAUNCH(K) hipLaunchKernelGGL(vpt_render_kernel<K>, grid, block, lds, st, s->d, pr, img, hit, rng, s->stack_cap)
+  /* implicit shaders: same longest-first schedule, costs from the previous launch on this layout (no pilot) */
+#define LAUNCH(K)                                                                                                \
+  do {                                                                                                          \
+    long long key_[10] = {pr.nslots, pr.width, pr.height, params->shader, params->camera, params->bounces,      \
+                          pr.rank, pr.nranks, pr.tile_w, pr.tile_h};                                            \
+    if (int rc_ = sched_prepare(s, grid.x, key_, st)) return rc_;                                               \
+    sched_cfg sch_ = {s->order_valid ? s->d_order : nullptr, s->d_cost};                                       \
+    hipLaunchKernelGGL(vpt_render_kernel<K>, grid, block, lds, st, s->d, pr, img, hit, rng, s->stack_cap, sch_); \
+    if (int rc_ = sched_update(s, grid.x, st)) return rc_;                                                      \
+  } while (0)
 #define LAUNCH_MESH(K)                                                                                          \
   do {                                                                                                          \
     if (use_stream_pipeline()) {                                                                                \

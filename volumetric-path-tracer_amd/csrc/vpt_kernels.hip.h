@@ -79,15 +79,26 @@ VPT_DEV bool survive(f3& weight, int bounce, rng_t& rng) {
   return true;
 }
 
+// Launch schedule.  A wave's 64 pixels run all their samples in sequence, so a wave's duration is fixed by its
+// tile's content and varies 15x across 03_volume; in tile order the launch ends with a third of the GPU idle
+// behind a few long waves.  Every wave records its duration; the next launch on the same layout starts the
+// waves longest first (order[] = wave indices by descending cost: LPT list scheduling).  Results do not depend
+// on the order (pixels are independent), only the makespan does.
+struct sched_cfg {
+  const int* order;   // blockIdx.x -> wave index, or null: identity
+  unsigned*  cost;    // per wave: duration of this launch in 100 MHz ticks, or null
+};
 template <int SH>
 __global__ void __launch_bounds__(VPT_BLOCK) vpt_render_kernel(DScene sc, DParams pr, float4* __restrict__ image,
-    int* __restrict__ hits, ulonglong2* __restrict__ rngs, int stack_cap) {
+    int* __restrict__ hits, ulonglong2* __restrict__ rngs, int stack_cap, sched_cfg sched) {
   extern __shared__ int lds_stack[];
   lane_stack stk;
   stk.base = lds_stack + threadIdx.x;
   stk.cap  = stack_cap;
+  const unsigned long long wave_start = wall_clock64();
+  const int wave = sched.order ? sched.order[blockIdx.x] : (int)blockIdx.x;
 
-  int slot = blockIdx.x * VPT_BLOCK + threadIdx.x;
+  int slot = wave * VPT_BLOCK + threadIdx.x;
   int px = 0, py = 0;
   if (slot >= pr.nslots || !slot_to_pixel(pr, slot, px, py)) return;   // padding lanes own no pixel
 
@@ -304,6 +315,10 @@ __global__ void __launch_bounds__(VPT_BLOCK) vpt_render_kernel(DScene sc, DParam
   ulonglong2 r_out;
   r_out.x = rng.state, r_out.y = rng.inc;
   rngs[slot] = r_out;
+  if (sched.cost && threadIdx.x == 0) {
+    unsigned long long dt = wall_clock64() - wave_start;
+    sched.cost[wave] = dt < 0xffffffffull ? (unsigned)dt : 0xffffffffu;
+  }
 }
 
 // ---- state layout conversion and output resolve ---------------------------------------------

@@ -34,15 +34,6 @@
 // (ref, t0) stack of one lane: the first `cap` entries live in LDS (entry-major: conflict-free), deeper
 // ones in a per-launch HBM array (entry-major too: coalesced).  `cap` covers what traversals use in
 // practice; the HBM part only makes the worst case (three pending siblings on every quad level) safe.
-// Launch schedule.  A wave's 64 pixels run all their samples in sequence, so a wave's duration is fixed by its
-// tile's content and varies 15x across 03_volume; in tile order the launch ends with a third of the GPU idle
-// behind a few long waves.  Every wave records its duration; the next launch on the same layout starts the
-// waves longest first (order[] = wave indices by descending cost: LPT list scheduling).  Results do not depend
-// on the order (pixels are independent), only the makespan does.
-struct sched_cfg {
-  const int* order;   // blockIdx.x -> wave index, or null: identity
-  unsigned*  cost;    // per wave: duration of this launch in 100 MHz ticks, or null
-};
 struct stack_cfg {
   int        cap;      // entries per lane in LDS
   int        spill;    // entries per lane in HBM

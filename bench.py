@@ -6,7 +6,9 @@ tests/03_volume, --shader volpathtrace --bounces 64, 1280 wide (x533: camera asp
 
 A *step* is one launch of the hot path over the whole frame: `--spp` (256) samples for every
 pixel, with the pixel state (radiance sums, hit counts, PCG32 streams) already resident in HBM in
-the tile-major layout of include/vpt.h.  With N GPUs the frame is cut into 8x8-pixel tiles dealt
+the tile-major layout of include/vpt.h.  Launches start their waves longest first, using the per-wave
+durations the previous launch on the same layout recorded; the very first launch of a
+process measures them with a one-sample pilot, which therefore falls into the warm-up.  With N GPUs the frame is cut into 8x8-pixel tiles dealt
 round-robin to the ranks (tile t -> rank t % N); each step ends with an RCCL all_gather of the
 ranks' tile buffers over xGMI and a resolve kernel on every rank.  Scaling is
 reported as WEAK: the per-GPU pixel count is fixed, i.e. the frame is 1280*sqrt(N) wide (N=8 ->

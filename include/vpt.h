@@ -260,8 +260,12 @@ int vpt_state_upload(const vpt_layout* layout, const float* image_rgba, const in
 int vpt_state_download(const vpt_layout* layout, const void* d_image, const void* d_hits,
                        const void* d_rng, float* image_rgba, int32_t* hits, uint64_t* rng,
                        void* stream);
-/* nsamples passes over this rank's pixels; asynchronous on `stream` (hipStream_t).
- * `first_sample` is state.samples before the call (selects the samples==1 preview branch). */
+/* nsamples passes over this rank's pixels; asynchronous on `stream` (hipStream_t).  params->samples == 1
+ * selects the pixel-centre preview branch (yocto_pathtrace.cpp:1059-1068).
+ * Scheduling: a wave renders all samples of its 64 pixels, so the scene handle remembers how long every
+ * wave of the last launch took and starts the next launch on the same layout / camera / shader longest wave
+ * first.  Without such a record and with nsamples >= 16, the first sample is rendered by a separate pilot
+ * launch that takes the measurement.  Neither changes the result (pixels are independent, batching is exact). */
 int vpt_render_device(vpt_scene* scene, const vpt_params* params, const vpt_layout* layout,
                       int nsamples, void* d_image, void* d_hits, void* d_rng, void* stream);
 /* get_render (yocto_pathtrace.cpp:1105-1116) on device: gathered tile-major float4 sums of ALL

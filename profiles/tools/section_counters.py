@@ -1,5 +1,7 @@
+"""Section counters / timers of the diagnostic build (make the library with -DVPT_COUNTERS, point VPT_HIP_LIB at it).
+Run from the repo root on a GPU box: VPT_HIP_LIB=$PWD/volumetric-path-tracer_amd/libvpt_hip_cnt.so python profiles/tools/section_counters.py"""
 import os, sys, ctypes
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
 import numpy as np, vpt_loader
 vpt = vpt_loader.load()
 lib = ctypes.CDLL(os.environ['VPT_HIP_LIB'])

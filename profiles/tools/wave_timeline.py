@@ -1,5 +1,7 @@
+"""Occupancy timeline of one launch from per-wave start/end stamps (library built with -DVPT_WAVE_TIMES).
+Run from the repo root on a GPU box: VPT_HIP_LIB=$PWD/volumetric-path-tracer_amd/libvpt_hip_wt.so python profiles/tools/wave_timeline.py"""
 import os, sys, ctypes
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
 import numpy as np, vpt_loader
 vpt = vpt_loader.load()
 lib = ctypes.CDLL(os.environ['VPT_HIP_LIB'])

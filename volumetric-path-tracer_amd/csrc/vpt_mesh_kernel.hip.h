@@ -75,8 +75,11 @@ VPT_DEV lane_stack2<SPILL> make_lane_stack(int* lds, const stack_cfg& cfg) {
 #define VPT_BOX_K 1.00000024f
 
 // intersect_bbox(ray, dinv, bbox) (yocto_geometry.h:858-868), also returning the entry distance
+VPT_DEV bool slab_pass(f3 it_min, f3 it_max, float tmin, float tmax, float& t0);
 VPT_DEV bool box_pass(f3 bmin, f3 bmax, f3 o, f3 dinv, float tmin, float tmax, float& t0) {
-  f3 it_min = (bmin - o) * dinv, it_max = (bmax - o) * dinv;
+  return slab_pass((bmin - o) * dinv, (bmax - o) * dinv, tmin, tmax, t0);
+}
+VPT_DEV bool slab_pass(f3 it_min, f3 it_max, float tmin, float tmax, float& t0) {
   f3 lo = vmin3(it_min, it_max), hi = vmax3(it_min, it_max);
   t0       = fmax_(max3(lo), tmin);
   float t1 = fmin_(min3(hi), tmax);
@@ -98,6 +101,17 @@ VPT_DEV bool box_test(bool slow, f3 bmin, f3 bmax, f3 o, f3 dinv, float tmin, fl
   return box_pass_fast(bmin, bmax, o, dinv, tmin, tmax, t0);
 }
 VPT_DEV bool has_zero(f3 d) { return d.x == 0 || d.y == 0 || d.z == 0; }
+// a ray whose slab products can be NaN (0 * inf): a zero direction component, or one so small that 1/d overflows
+VPT_DEV bool nan_prone(f3 d, f3 dinv) {
+  return has_zero(d) || !(__builtin_fabsf(dinv.x) < VPT_FLT_MAX && __builtin_fabsf(dinv.y) < VPT_FLT_MAX && __builtin_fabsf(dinv.z) < VPT_FLT_MAX);
+}
+// near-plane half of the fast test: with a finite non-zero 1/d, (lo - o)/d <= (hi - o)/d for d > 0 and >= for
+// d < 0 (float - and * are monotone), so min/max of the two slab products per axis is a choice by the sign of d
+VPT_DEV bool slab_pass_signed(float nx, float ny, float nz, float fx, float fy, float fz, float tmin, float tmax, float& t0) {
+  t0       = hw_max3(hw_max(nx, ny), nz, tmin);
+  float t1 = hw_min3(hw_min(fx, fy), fz, tmax) * VPT_BOX_K;
+  return t0 <= t1;
+}
 
 // One BVH query.  only_instance < 0: intersect_bvh(bvh, scene, ray) (yocto_bvh.cpp:800-871);
 // only_instance >= 0: intersect_bvh(bvh, scene, instance, ray) (:874-881).  Ray = {wo, wd, 1e-4, flt_max}.
@@ -124,7 +138,7 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
   float tmax = VPT_FLT_MAX;
   const f3   winv = rcp3_exact(wd);
   const int  wsgn = sign_bits(winv);
-  const bool wslow = has_zero(wd);
+  const bool wslow = nan_prone(wd, winv);
   f3    co = wo, cd = wd, cinv = winv;
   int   csgn = wsgn;
   bool  slow = wslow;
@@ -165,7 +179,7 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
       if (general) {
         frame inv = unpack_frame(e[0], e[1], e2);
         co = transform_point(inv, wo), cd = transform_vector(inv, wd);
-        cinv = rcp3_exact(cd), slow = has_zero(cd);
+        cinv = rcp3_exact(cd), slow = nan_prone(cd, cinv);
       } else {
         co = mk3(wo.x + e2.y, wo.y + e2.z, wo.z + e2.w);
       }
@@ -204,7 +218,7 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
         if (!__float_as_int(e5.z) || any_slow) {
           frame inv = unpack_frame(e[0], e[1], e2);
           f3    ld  = transform_vector(inv, wd);
-          lo = transform_point(inv, wo), linv = rcp3_exact(ld), lslow = has_zero(ld);
+          lo = transform_point(inv, wo), linv = rcp3_exact(ld), lslow = nan_prone(ld, linv);
         } else {
           lo = mk3(wo.x + e2.y, wo.y + e2.z, wo.z + e2.w), linv = winv, lslow = false;
         }
@@ -226,20 +240,31 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
     while (cur >= 0) {
       VPT_CNT(CNT_NODE);
       const float4* q = wn + 8 * (long long)cur;
-      float4 lx = q[0], ly = q[1], lz = q[2], hx = q[3], hy = q[4], hz = q[5], qr = q[6];
+      // rows of the node: lo.x lo.y lo.z hi.x hi.y hi.z (four children each).  The near plane of an axis is
+      // the lo row for a positive direction, the hi row for a negative one: fetch them by the ray's signs
+      int    ix = (csgn & 1) ? 3 : 0, iy = (csgn & 2) ? 4 : 1, iz = (csgn & 4) ? 5 : 2;
+      float4 nx = q[ix], fx = q[3 - ix], ny = q[iy], fy = q[5 - iy], nz = q[iz], fz = q[7 - iz], qr = q[6];
       int    meta = __float_as_int(q[7].x);
+      float4 anx = make_float4((nx.x - co.x) * cinv.x, (nx.y - co.x) * cinv.x, (nx.z - co.x) * cinv.x, (nx.w - co.x) * cinv.x);
+      float4 afx = make_float4((fx.x - co.x) * cinv.x, (fx.y - co.x) * cinv.x, (fx.z - co.x) * cinv.x, (fx.w - co.x) * cinv.x);
+      float4 any = make_float4((ny.x - co.y) * cinv.y, (ny.y - co.y) * cinv.y, (ny.z - co.y) * cinv.y, (ny.w - co.y) * cinv.y);
+      float4 afy = make_float4((fy.x - co.y) * cinv.y, (fy.y - co.y) * cinv.y, (fy.z - co.y) * cinv.y, (fy.w - co.y) * cinv.y);
+      float4 anz = make_float4((nz.x - co.z) * cinv.z, (nz.y - co.z) * cinv.z, (nz.z - co.z) * cinv.z, (nz.w - co.z) * cinv.z);
+      float4 afz = make_float4((fz.x - co.z) * cinv.z, (fz.y - co.z) * cinv.z, (fz.z - co.z) * cinv.z, (fz.w - co.z) * cinv.z);
       float  t0, t1, t2, t3;
       bool   p0, p1, p2, p3;
       if (__builtin_amdgcn_ballot_w64(slow) != 0) {   // some lane may meet 0 * inf: the reference's NaN-asymmetric form for all
-        p0 = box_pass(mk3(lx.x, ly.x, lz.x), mk3(hx.x, hy.x, hz.x), co, cinv, tmin, tmax, t0);
-        p1 = box_pass(mk3(lx.y, ly.y, lz.y), mk3(hx.y, hy.y, hz.y), co, cinv, tmin, tmax, t1);
-        p2 = box_pass(mk3(lx.z, ly.z, lz.z), mk3(hx.z, hy.z, hz.z), co, cinv, tmin, tmax, t2);
-        p3 = box_pass(mk3(lx.w, ly.w, lz.w), mk3(hx.w, hy.w, hz.w), co, cinv, tmin, tmax, t3);
+        // (lo - o) * inv and (hi - o) * inv are the same products, told apart again by the sign
+        bool sx = csgn & 1, sy = csgn & 2, sz = csgn & 4;
+        p0 = slab_pass(mk3(sx ? afx.x : anx.x, sy ? afy.x : any.x, sz ? afz.x : anz.x), mk3(sx ? anx.x : afx.x, sy ? any.x : afy.x, sz ? anz.x : afz.x), tmin, tmax, t0);
+        p1 = slab_pass(mk3(sx ? afx.y : anx.y, sy ? afy.y : any.y, sz ? afz.y : anz.y), mk3(sx ? anx.y : afx.y, sy ? any.y : afy.y, sz ? anz.y : afz.y), tmin, tmax, t1);
+        p2 = slab_pass(mk3(sx ? afx.z : anx.z, sy ? afy.z : any.z, sz ? afz.z : anz.z), mk3(sx ? anx.z : afx.z, sy ? any.z : afy.z, sz ? anz.z : afz.z), tmin, tmax, t2);
+        p3 = slab_pass(mk3(sx ? afx.w : anx.w, sy ? afy.w : any.w, sz ? afz.w : anz.w), mk3(sx ? anx.w : afx.w, sy ? any.w : afy.w, sz ? anz.w : afz.w), tmin, tmax, t3);
       } else {
-        p0 = box_pass_fast(mk3(lx.x, ly.x, lz.x), mk3(hx.x, hy.x, hz.x), co, cinv, tmin, tmax, t0);
-        p1 = box_pass_fast(mk3(lx.y, ly.y, lz.y), mk3(hx.y, hy.y, hz.y), co, cinv, tmin, tmax, t1);
-        p2 = box_pass_fast(mk3(lx.z, ly.z, lz.z), mk3(hx.z, hy.z, hz.z), co, cinv, tmin, tmax, t2);
-        p3 = box_pass_fast(mk3(lx.w, ly.w, lz.w), mk3(hx.w, hy.w, hz.w), co, cinv, tmin, tmax, t3);
+        p0 = slab_pass_signed(anx.x, any.x, anz.x, afx.x, afy.x, afz.x, tmin, tmax, t0);
+        p1 = slab_pass_signed(anx.y, any.y, anz.y, afx.y, afy.y, afz.y, tmin, tmax, t1);
+        p2 = slab_pass_signed(anx.z, any.z, anz.z, afx.z, afy.z, afz.z, tmin, tmax, t2);
+        p3 = slab_pass_signed(anx.w, any.w, anz.w, afx.w, afy.w, afz.w, tmin, tmax, t3);
       }
       // slots 0,1 = children of child 0, slots 2,3 = children of child 1 of the binary node.  The reference
       // pushes child 0 then child 1 when the ray is negative along the node's axis (child 1 popped first),
@@ -332,7 +357,7 @@ VPT_DEV float small_light_pdf(const DScene& sc, int light_id, float4 r6, float4 
   frame  inv   = unpack_frame(rec[0], rec[1], rec[2]);
   f3     ld    = transform_vector(inv, direction);
   f3     linv  = rcp3_exact(ld);
-  bool   lslow = has_zero(ld);
+  bool   lslow = nan_prone(ld, linv);
   int    count = (__float_as_int(r7.w) >> 8) & 15;
   float  area  = r6.w;
   float  lpdf  = 0.0f;

@@ -88,8 +88,11 @@ struct sched_cfg {
   const int* order;   // blockIdx.x -> wave index, or null: identity
   unsigned*  cost;    // per wave: duration of this launch in 100 MHz ticks, or null
 };
+#ifndef VPT_K2_WAVES
+#define VPT_K2_WAVES 4   // measured on 06_gridsdf_synth: 2 -> 95, 3 -> 117, 4 -> 125, 5 -> 116, 6 -> 108, 8 -> 96 Msamples/s
+#endif
 template <int SH>
-__global__ void __launch_bounds__(VPT_BLOCK) vpt_render_kernel(DScene sc, DParams pr, float4* __restrict__ image,
+__global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DScene sc, DParams pr, float4* __restrict__ image,
     int* __restrict__ hits, ulonglong2* __restrict__ rngs, int stack_cap, sched_cfg sched) {
   extern __shared__ int lds_stack[];
   lane_stack stk;

@@ -282,6 +282,12 @@ int vpt_last_kernel_ms(vpt_scene* scene, float* ms);
  * patterns on `device` and returns in *mismatches how many in-range inputs differ from the IEEE quotient
  * (must be 0), in *fallbacks how many patterns are out of range (handled by a real division). */
 int vpt_selftest_reciprocal(int device, unsigned long long* mismatches, unsigned long long* fallbacks);
+/* Device self-test of the search structure that replaces std::upper_bound over a light's CDF in sample_discrete
+ * (yocto_sampling.h:385-390; 21 dependent probes on a 2 M-texel environment map): `n` probe values - CDF
+ * entries, their float neighbours, both ends, uniform values - are looked up through the guide table / 16-ary
+ * levels and through the plain binary search; *mismatches must come back 0.  *indexed: 0 the light's CDF is
+ * short and uses the binary search itself, 1 16-ary levels, 2 levels + guide table. */
+int vpt_selftest_light_cdf(vpt_scene* scene, int light, int n, unsigned long long* mismatches, int* indexed);
 
 #ifdef __cplusplus
 }

@@ -269,3 +269,22 @@ def test_streaming_pipeline_is_bit_identical(vpt, tmp_path, scene_file, shader, 
     dev.pathtrace_samples(st, p, spp)
     assert np.array_equal(got["rngs"], st.rngs) and np.array_equal(got["hits"], st.hits)
     assert np.array_equal(got["image"].view(np.uint32), st.image.view(np.uint32))
+
+
+@pytest.mark.parametrize("scene_file", ["03_volume/volume.json", "05_head1ss_sub/head1ss_sub.json"])
+def test_light_cdf_index_equals_upper_bound(vpt, scene_file):
+    """The guide table + 16-ary levels over a large light CDF must return std::upper_bound's index for CDF
+    entries, their float neighbours, both ends of the range and uniform values (2^20 probes per light)."""
+    scene = vpt.HostScene(os.path.join(GOLDEN, "scenes", scene_file))
+    dev = vpt.DeviceScene(scene, 0)
+    kinds = []
+    light = 0
+    while True:
+        try:
+            bad, indexed = dev.selftest_light_cdf(light)
+        except vpt.VptError:
+            break
+        assert bad == 0, (light, bad)
+        kinds.append(indexed)
+        light += 1
+    assert light >= 1 and 2 in kinds, kinds   # every test scene has a textured environment light: guide table in use

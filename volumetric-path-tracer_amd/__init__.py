@@ -101,6 +101,7 @@ hip.vpt_render_device.argtypes = [_p, C.POINTER(VptParams), C.POINTER(VptLayout)
 hip.vpt_resolve_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
 hip.vpt_last_kernel_ms.argtypes = [_p, C.POINTER(C.c_float)]
 hip.vpt_selftest_reciprocal.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+hip.vpt_selftest_light_cdf.argtypes = [_p, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
 host.vpth_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
 host.vpth_scene_load.restype = _p
 host.vpth_scene_free.argtypes = [_p]
@@ -194,6 +195,12 @@ class DeviceScene:
         abi = params.to_abi()
         _check(hip.vpt_render_device(self.handle, C.byref(abi), C.byref(layout), nsamples, d_image, d_hits, d_rng,
                                      stream), "vpt_render_device")
+
+    def selftest_light_cdf(self, light: int, n: int = 1 << 20):
+        """(mismatches, indexed) of the light-CDF search structure against the plain binary search (include/vpt.h)"""
+        bad, indexed = C.c_ulonglong(0), C.c_int(0)
+        _check(hip.vpt_selftest_light_cdf(self.handle, light, n, C.byref(bad), C.byref(indexed)), "vpt_selftest_light_cdf")
+        return bad.value, indexed.value
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

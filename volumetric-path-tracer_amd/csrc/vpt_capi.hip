@@ -29,6 +29,39 @@ __global__ void vpt_light_setup_kernel(DScene sc, float4* out) {
   out[20 * l + 5 * k + 4] = make_float4(n.x, n.y, n.z, __int_as_float(sh.is_triangles ? 1 : 0));
 }
 
+// search_light_cdf against the plain binary search on the same CDF: values at, just below and just above CDF
+// entries, uniform ones, and the ends of the range; out[0] = mismatches
+__global__ void vpt_light_cdf_selftest_kernel(DScene sc, int light_id, int n, unsigned long long* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const vpt_light& light = sc.lights[light_id];
+  const float*     cdf   = sc.light_cdf + light.cdf_offset;
+  const int        len   = light.cdf_len;
+  float back = cdf[len - 1];
+  // the wave votes inside search_light_cdf: keep all lanes in, flag the surplus ones instead of returning
+  bool     live = i < n;
+  unsigned h    = (unsigned)i * 2654435761u + 12345u;
+  h ^= h >> 15, h *= 2246822519u, h ^= h >> 13;
+  float v = cdf[h % (unsigned)len];
+  switch (i & 7) {
+    case 0: break;
+    case 1: v = __uint_as_float(__float_as_uint(v) - (v > 0 ? 1u : 0u)); break;
+    case 2: v = __uint_as_float(__float_as_uint(v) + 1u); break;
+    case 3: v = 0.0f; break;
+    case 4: v = back; break;
+    default: v = back * ((h >> 8) * (1.0f / 16777216.0f)); break;
+  }
+  float r = clampf(v, 0.0f, back - 0.00001f);
+  int a = search_light_cdf(sc, light_id, r);
+  int lo = 0, cnt = len;   // std::upper_bound, as sample_discrete
+  while (cnt > 0) {
+    int half = cnt >> 1;
+    if (!(r < cdf[lo + half])) lo += half + 1, cnt -= half + 1;
+    else cnt = half;
+  }
+  int b = lo < len ? lo : len - 1;
+  if (live && a != b) atomicAdd(&out[0], 1ull);
+}
+
 // all 2^32 operands of rcp_newton (vpt_mesh_kernel.hip.h) against the IEEE quotient; out[0] = mismatches, out[1] = out of range
 __global__ void vpt_reciprocal_selftest_kernel(unsigned long long* out) {
   unsigned long long bad = 0, skipped = 0;
@@ -940,6 +973,23 @@ int vpt_selftest_reciprocal(int device, unsigned long long* mismatches, unsigned
   int rc = hipMemcpy(h, d, 16, hipMemcpyDeviceToHost) == hipSuccess ? VPT_OK : fail(VPT_ERR_HIP, "reciprocal self-test failed to run");
   (void)hipFree(d);
   *mismatches = h[0], *fallbacks = h[1];
+  return rc;
+}
+
+int vpt_selftest_light_cdf(vpt_scene* s, int light, int n, unsigned long long* mismatches, int* indexed) {
+  if (!s || !mismatches || !indexed || n <= 0) return fail(VPT_ERR_INVALID_ARG, "bad argument");
+  if (light < 0 || light >= s->d.num_lights) return fail(VPT_ERR_INVALID_ARG, "light %d out of range", light);
+  HIP_TRY(hipSetDevice(s->device));
+  DCdfIndex ix;
+  HIP_TRY(hipMemcpy(&ix, s->d.light_index + light, sizeof(ix), hipMemcpyDeviceToHost));
+  *indexed = ix.levels > 0 ? (ix.guide_buckets > 0 ? 2 : 1) : 0, *mismatches = 0;
+  if (!ix.levels) return VPT_OK;   // short CDFs use the reference's binary search itself
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 8));
+  HIP_TRY(hipMemset(d, 0, 8));
+  hipLaunchKernelGGL(vpt_light_cdf_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, s->d, light, n, d);
+  int rc = hipMemcpy(mismatches, d, 8, hipMemcpyDeviceToHost) == hipSuccess ? VPT_OK : fail(VPT_ERR_HIP, "light CDF self-test failed to run");
+  (void)hipFree(d);
   return rc;
 }
 

@@ -463,15 +463,12 @@ VPT_DEV int count_not_above(const float* g, float r) {
          (int)!(r < b.z) + (int)!(r < b.w) + (int)!(r < c.x) + (int)!(r < c.y) + (int)!(r < c.z) + (int)!(r < c.w) +
          (int)!(r < d.x) + (int)!(r < d.y) + (int)!(r < d.z) + (int)!(r < d.w);
 }
-// the same index through the light's 16-ary levels (DCdfIndex, vpt_device.h)
-VPT_DEV int sample_light_cdf(const DScene& sc, int light_id, float r) {
+// std::upper_bound(cdf, cdf + n, r) clamped to n - 1, through the light's guide table and 16-ary levels
+// (DCdfIndex, vpt_device.h); r is already scaled and clamped as sample_discrete does
+VPT_DEV int search_light_cdf(const DScene& sc, int light_id, float r) {
   const vpt_light& light = sc.lights[light_id];
-  const float*     cdf   = sc.light_cdf + light.cdf_offset;
   const int        n     = light.cdf_len;
   const DCdfIndex& ix    = sc.light_index[light_id];
-  if (ix.levels == 0) return sample_discrete(cdf, n, r);
-  float back = cdf[n - 1];
-  r = clampf(r * back, 0.0f, back - 0.00001f);
   if (ix.guide_buckets > 0) {   // bracket from the guide table; short brackets are resolved with one 16-wide fetch
     int  b  = (int)(r * ix.guide_scale);
     int2 lh = sc.light_guide[ix.guide_offset + (b < ix.guide_buckets ? b : ix.guide_buckets - 1)];
@@ -490,6 +487,14 @@ VPT_DEV int sample_light_cdf(const DScene& sc, int light_id, float r) {
   // below finds its first entry > r inside that group; the +inf padding is never counted
   for (int k = ix.levels - 2; k >= 0; k--) idx = 16 * idx + count_not_above(sc.light_index_pool + ix.offset[k] + 16 * (long long)idx, r);
   return idx;
+}
+VPT_DEV int sample_light_cdf(const DScene& sc, int light_id, float r) {
+  const vpt_light& light = sc.lights[light_id];
+  const float*     cdf   = sc.light_cdf + light.cdf_offset;
+  const int        n     = light.cdf_len;
+  if (sc.light_index[light_id].levels == 0) return sample_discrete(cdf, n, r);
+  float back = cdf[n - 1];
+  return search_light_cdf(sc, light_id, clampf(r * back, 0.0f, back - 0.00001f));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,22 +12,31 @@
 //    (yocto_pathtrace.cpp:363-378) run through the same traversal as extra trips (state ST_LPDF).
 //    Lights whose shape is a single leaf (<= 4 primitives, e.g. the area-light quads of the test
 //    scenes) are walked inline in the shading phase instead (small_light_pdf): no trip, no stack;
-//  * WHILE-WHILE TRAVERSAL over 64-byte "wide" nodes (both child boxes + refs, one 4 x dwordx4 fetch):
-//    lanes first pop/box-test until each holds a leaf (or is done), then all test leaf primitives
-//    together — primitive tests are never executed for a handful of lanes while the rest wait;
-//  * (ref, t0) stacks in LDS, entry-major, conflict-free; box tests use v_min3/v_max3-style code when
-//    the ray has no zero direction component (no NaN possible, identical results) and the reference's
-//    NaN-asymmetric ternary form otherwise.
+//  * WHILE-WHILE TRAVERSAL over 128-byte QUAD NODES: one step tests the boxes of the four grandchildren of
+//    a node of the reference's binary BVH (two levels per step); lanes walk internal nodes until each
+//    holds a leaf (or is done), then all test leaf primitives together, then instance entries — unlike
+//    work is never interleaved in one loop body;
+//  * (ref, t0) stacks in LDS, entry-major, conflict-free (HBM overflow for BVHs whose worst case does not
+//    fit); near / far planes chosen by the ray's sign and v_min3/v_max3 when no slab product can be NaN
+//    (identical results), the reference's NaN-asymmetric ternary form otherwise;
+//  * small scenes test the root boxes of all instances in lockstep at the start of a query (tmax = inf);
+//  * waves are launched longest first from the durations the previous launch recorded (sched_cfg).
 //
-// Exactness of the wide-node traversal.  The reference pops a node, tests its box against the
-// current ray.tmax and only then looks at the children (yocto_bvh.cpp:728-750).  Here a child's box
-// is tested when the parent is visited: t0 = max(max3(lo), tmin), t1 = min(min3(hi), tmax)*1.00000024f.
-// tmax only shrinks, so a child failing now would also fail at its pop: not pushing it is exact.  A
-// child passing now is pushed with t0; at its pop the reference's test with the smaller tmax' equals
-// (t0 <= far*k) && (t0 <= tmax'*k) because x -> x*k is monotone; the first factor is known true, so
-// the pop test `t0 <= tmax'*k` is the reference's test bit for bit.  Visit order (near child on top,
-// yocto_bvh.cpp:744-750) and primitive order inside leaves are unchanged (a lane that reached a leaf
-// does nothing until it has tested it), so even exact ties in distance resolve as in the reference.
+// Exactness of the quad-node traversal.  The reference pops a node, tests its box against the current
+// ray.tmax and only then looks at the children (yocto_bvh.cpp:728-750).  Here a node's box is tested when
+// its grandparent is visited: t0 = max(near planes, tmin), t1 = min(far planes, tmax) * 1.00000024f.
+//  - tmax only shrinks, so a box failing now would also fail at its pop: not pushing it is exact;
+//  - a box passing now is pushed with t0; at its pop the reference's test with the smaller tmax' equals
+//    (t0 <= far*k) && (t0 <= tmax'*k) because x -> x*k is monotone; the first factor is known true, so the
+//    pop test `t0 <= tmax'*k` is the reference's test bit for bit;
+//  - the skipped middle level: a child's box lies inside its parent's and float -, *, min, max are monotone,
+//    so t0(parent) <= t0(child): a child passing its own pop-time test implies the parent passed its test
+//    (earlier, with a larger tmax); a parent that would have failed has no passing child;
+//  - visit order: the reference pushes child 0 then child 1 when the ray is negative along the node's axis
+//    (child 1 popped first) and repeats that when the child is popped, so the grandchildren are visited
+//    [group by the node's axis][member by the child's axis]; primitive order inside leaves is unchanged (a
+//    lane that reached a leaf does nothing until it has tested it).  Even exact ties in distance resolve
+//    as in the reference.
 #pragma once
 #include "vpt_kernels.hip.h"
 
@@ -116,12 +125,12 @@ VPT_DEV bool slab_pass_signed(float nx, float ny, float nz, float fx, float fy, 
 // One BVH query.  only_instance < 0: intersect_bvh(bvh, scene, ray) (yocto_bvh.cpp:800-871);
 // only_instance >= 0: intersect_bvh(bvh, scene, instance, ray) (:874-881).  Ray = {wo, wd, 1e-4, flt_max}.
 //
-// Loop shape: the lane's next action is kept in `cur` (>= 0: internal wide node of the current level,
+// Loop shape: the lane's next action is kept in `cur` (>= 0: quad node of the current level,
 // VPT_NONE: nothing left at this level, other negatives: a leaf).  Each trip of the outer loop runs up
 // to three phases, each entered only by the lanes that need it, so unlike work is never interleaved
 // inside one loop body:
-//   A  internal nodes: fetch, two box tests, descend into the first-visited child directly (it would
-//      be popped next with the same tmax, so its pop test is a tautology) and push the other one;
+//   A  quad nodes: fetch, four box tests, descend into the first-visited passing child directly (it would
+//      be popped next with the same tmax, so its pop test is a tautology) and push the others, last first;
 //   B  shape leaf: primitive tests in order;
 //   C  scene leaf / pending instances: transform the ray, test the instance's root box (the test the
 //      reference's shape-level loop does first, yocto_bvh.cpp:728-733); instances that miss it are
@@ -158,7 +167,6 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
     }
     return VPT_NONE;
   };
-  // enter pending instances (pend = start<<4 | count) until one passes its root test; else pop
   // Phase C.  Enter the pending instances of a scene leaf (pend = first slot << 4 | count) one after another,
   // from their 96-byte enter records (vpt_device.h), until one passes the root-box test the reference's
   // shape-level loop does first (yocto_bvh.cpp:728-733); instances that miss it never leave world space.

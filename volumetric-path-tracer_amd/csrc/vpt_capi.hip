@@ -537,6 +537,7 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   UP(upload(s, (const float4*)d.scene_bvh_nodes, 2LL * d.num_scene_bvh_nodes, &D.scene_nodes));
   UP(upload(s, d.scene_bvh_prims, d.num_scene_bvh_prims, &D.scene_prims));
   UP(upload(s, (const float4*)d.shape_bvh_nodes, 2LL * d.num_shape_bvh_nodes, &D.shape_nodes));
+  leafs.resize(leafs.size() + 8, make_float4(0, 0, 0, 0));   // phase B fetches one record ahead of the one it tests
   UP(upload(s, leafs, &D.leaf_prims));
   UP(upload(s, scene_wnodes, &D.scene_wnodes));
   UP(upload(s, shape_wnodes, &D.shape_wnodes));

@@ -335,10 +335,15 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
       int start = code >> 4, num = code & 15;
       VPT_CNT(CNT_LEAF);
       VPT_T0(TM_PRIMS);
+      // software-pipelined: the next primitive's record is in flight while this one is tested (a leaf's
+      // records are contiguous; one past the last primitive of the pool is still inside the padded array)
+      const float4* rec = leafs + 4 * (long long)start;
+      float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
       for (int k = 0; k < num; k++) {
         VPT_CNT(CNT_PRIM);
-        const float4* rec = leafs + 4 * (long long)(start + k);
-        float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+        rec += 4;
+        n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
         if (intersect_quad(co, cd, tmin, tmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), r.uv, r.distance))
           r.hit = true, r.element = __float_as_int(r0.w), r.instance = cur_inst, tmax = r.distance;
       }

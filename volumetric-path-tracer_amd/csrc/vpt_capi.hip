@@ -426,7 +426,7 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
 
   std::vector<DShape> shapes((size_t)d.num_shapes);
   std::vector<int4>   elems;
-  std::vector<float4> leafs, shape_wnodes, scene_wnodes;
+  std::vector<float4> leafs, leaf_attrs, shape_wnodes, scene_wnodes;
   int max_shape_depth = 0, max_shape_need4 = 0;
   for (int i = 0; i < d.num_shapes; i++) {
     const vpt_shape& sh = d.shapes[i];
@@ -458,6 +458,15 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
         memcpy(&p.w, &tag, 4);
         leafs.push_back(p);
       }
+      // the corners' normals, then their texcoords (zeros where the shape has none: never read then)
+      float tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int c = 0; c < 4; c++) {
+        int v = c == 0 ? q.x : c == 1 ? q.y : c == 2 ? q.z : q.w;
+        leaf_attrs.push_back(sh.normal_offset >= 0 ? normals[(size_t)sh.normal_offset + v] : make_float4(0, 0, 0, 0));
+        if (sh.texcoord_offset >= 0) tc[2 * c] = texcoords[(size_t)sh.texcoord_offset + v].x, tc[2 * c + 1] = texcoords[(size_t)sh.texcoord_offset + v].y;
+      }
+      leaf_attrs.push_back(make_float4(tc[0], tc[1], tc[2], tc[3]));
+      leaf_attrs.push_back(make_float4(tc[4], tc[5], tc[6], tc[7]));
     }
     o.wnode_offset = (int)(shape_wnodes.size() / 8);
     int need4 = 0;
@@ -503,6 +512,11 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
     pack_frame(hinverse(f, true), instances[i].inv);
     pack_frame(f, instances[i].fwd);
     instances[i].shape = d.instances[i].shape, instances[i].material = d.instances[i].material;
+    {
+      const vpt_shape& sh = d.shapes[d.instances[i].shape];
+      instances[i].shape_flags = (sh.num_triangles != 0 ? VPT_SHP_TRIANGLES : 0) | (sh.normal_offset >= 0 ? VPT_SHP_NORMALS : 0) |
+                                 (sh.texcoord_offset >= 0 ? VPT_SHP_TEXCOORDS : 0) | (sh.color_offset >= 0 ? VPT_SHP_COLORS : 0);
+    }
     instances[i].translation_only = f.x.x == 1 && f.x.y == 0 && f.x.z == 0 && f.y.x == 0 && f.y.y == 1 && f.y.z == 0 &&
                                     f.z.x == 0 && f.z.y == 0 && f.z.z == 1;
   }
@@ -539,6 +553,7 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   UP(upload(s, (const float4*)d.shape_bvh_nodes, 2LL * d.num_shape_bvh_nodes, &D.shape_nodes));
   leafs.resize(leafs.size() + 8, make_float4(0, 0, 0, 0));   // phase B fetches one record ahead of the one it tests
   UP(upload(s, leafs, &D.leaf_prims));
+  UP(upload(s, leaf_attrs, &D.leaf_attrs));
   UP(upload(s, scene_wnodes, &D.scene_wnodes));
   UP(upload(s, shape_wnodes, &D.shape_wnodes));
   UP(upload(s, enter, &D.scene_enter));

@@ -18,12 +18,15 @@
 
 #include "vpt.h"
 
+enum { VPT_SHP_TRIANGLES = 1, VPT_SHP_NORMALS = 2, VPT_SHP_TEXCOORDS = 4, VPT_SHP_COLORS = 8 };
+
 struct DInstance {       // 128 B
   float4 inv[3];         // inverse(frame, non_rigid=true): rows packed as x,y,z columns + o: see pack
   float4 fwd[3];
   int    shape, material;
   int    translation_only;   // rotation part is exactly the identity: local direction == world direction
-  int    pad[5];
+  int    shape_flags;        // VPT_SHP_* of its shape: shading then needs no DShape fetch
+  int    pad[4];
 };
 // A frame {x,y,z,o} (4 columns of 3) packed in 3 float4: {x.x,x.y,x.z,y.x} {y.y,y.z,z.x,z.y} {z.z,o.x,o.y,o.z}
 
@@ -113,6 +116,10 @@ struct DScene {
   // [7] = {root box hi.xyz, kind | count << 8} with kind = VPT_LIGHT_*.  light_prims: for single-leaf mesh lights,
   // 4 x 5 float4 per light: the leaf's primitives as corner positions (element id in p0.w) + the element's
   // world-space normal (eval_element_normal), computed on the device at scene creation.
+  // Vertex attributes per primitive slot, parallel to leaf_prims: 6 float4 = the four corners' normals, then
+  // their texcoords as 4 x float2.  A hit carries its slot, so position, normal and texcoord of the shading
+  // point are one fetch level away instead of instances[] -> shapes[] -> elems[] -> positions/normals/texcoords[].
+  const float4*    leaf_attrs;
   const float4*    light_rec;
   const float4*    light_prims;
   const DCdfIndex* light_index;      // per light: 16-ary search index over its CDF (levels == 0: plain binary search)

@@ -142,7 +142,7 @@ VPT_DEV bool slab_pass_signed(float nx, float ny, float nz, float fx, float fy, 
 template <class STK>
 VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const STK& stk) {
   hit_t r;
-  r.instance = -1, r.element = -1, r.uv = mk2(0, 0), r.distance = 0, r.hit = false;
+  r.instance = -1, r.element = -1, r.uv = mk2(0, 0), r.distance = 0, r.hit = false, r.prim = 0;
   const float tmin = VPT_RAY_EPS;
   float tmax = VPT_FLT_MAX;
   const f3   winv = rcp3_exact(wd);
@@ -345,7 +345,7 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
         rec += 4;
         n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
         if (intersect_quad(co, cd, tmin, tmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), r.uv, r.distance))
-          r.hit = true, r.element = __float_as_int(r0.w), r.instance = cur_inst, tmax = r.distance;
+          r.hit = true, r.element = __float_as_int(r0.w), r.instance = cur_inst, tmax = r.distance, r.prim = (int)((rec - sc.leaf_prims) >> 2) - 1;
       }
       cur = pop_valid();
       VPT_T1(TM_PRIMS);
@@ -563,9 +563,22 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
         if (!in_volume) {
           const DInstance& inst = sc.instances[h.instance];
           VPT_T0(TM_SURF_GEOM);
-          position = eval_position(sc, inst, h.element, h.uv);
-          normal   = eval_shading_normal(sc, inst, h.element, h.uv, outgoing);
-          m        = eval_material(sc, inst, h.element, h.uv);
+          const vpt_material& mat = sc.materials[inst.material];
+          f2 texcoord;
+          f4 color_shp = mk4(1, 1, 1, 1);
+          if ((inst.shape_flags & (VPT_SHP_NORMALS | VPT_SHP_COLORS)) == VPT_SHP_NORMALS) {
+            // the common case: everything about the shading point sits behind the hit's primitive slot
+            eval_surface_slot(sc, inst, h.prim, h.uv, position, normal, texcoord);
+          } else {   // no vertex normals (element normal) or vertex colours: through the element's vertex indices
+            position  = eval_position(sc, inst, h.element, h.uv);
+            normal    = eval_normal(sc, inst, h.element, h.uv);
+            texcoord  = eval_texcoord(sc, inst, h.element, h.uv);
+            color_shp = eval_color(sc, inst, h.element, h.uv);
+          }
+          // eval_shading_normal, yocto_scene.cpp:476-503
+          if (mat.normal_tex != VPT_INVALID) normal = eval_normalmap(sc, inst, h.element, h.uv, normal, mat.normal_tex);
+          if (mat.type != VPT_MAT_REFRACTIVE && !(dot(normal, outgoing) >= 0)) normal = -normal;
+          m = eval_material_at(sc, mat, texcoord, color_shp);
           VPT_T1(TM_SURF_GEOM);
           if (m.opacity < 1 && rand1f(rng) >= m.opacity) {
             ray = make_ray(position + ray.d * 1e-2f, ray.d);   // bounce -= 1; continue

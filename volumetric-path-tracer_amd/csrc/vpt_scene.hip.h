@@ -61,7 +61,7 @@ struct ray_t { f3 o, d; float tmin, tmax; };
 VPT_DEV ray_t make_ray(f3 o, f3 d) { ray_t r = {o, d, VPT_RAY_EPS, VPT_FLT_MAX}; return r; }
 VPT_DEV f3 ray_point(const ray_t& r, float t) { return r.o + r.d * t; }
 
-struct hit_t { int instance, element; f2 uv; float distance; bool hit; };
+struct hit_t { int instance, element; f2 uv; float distance; bool hit; int prim; };   // prim: slot in leaf_prims / leaf_attrs (quad-node traversal only)
 
 // intersect_triangle, yocto_geometry.h:786-819 (Moller-Trumbore, no epsilon)
 VPT_DEV bool intersect_triangle(f3 ro, f3 rd, float tmin, float tmax, f3 p0, f3 p1, f3 p2, f2& uv, float& dist) {
@@ -354,11 +354,9 @@ VPT_DEV void finish_material(mpoint& p, float trdepth) {
   else if (p.type == VPT_MAT_VOLUMETRIC) p.roughness = 0;
   else if (p.roughness < VPT_MIN_ROUGHNESS) p.roughness = 0;
 }
-VPT_DEV mpoint eval_material(const DScene& sc, const DInstance& inst, int element, f2 uv) {
-  const vpt_material& m  = sc.materials[inst.material];
-  f2 texcoord     = eval_texcoord(sc, inst, element, uv);
+// eval_material with the shading point's texcoord and shape colour already evaluated
+VPT_DEV mpoint eval_material_at(const DScene& sc, const vpt_material& m, f2 texcoord, f4 color_shp) {
   f4 emission_tex = eval_texture(sc, m.emission_tex, texcoord, true);
-  f4 color_shp    = eval_color(sc, inst, element, uv);
   f4 color_tex    = eval_texture(sc, m.color_tex, texcoord, true);
   f4 rough_tex    = eval_texture(sc, m.roughness_tex, texcoord, false);
   f4 scatter_tex  = eval_texture(sc, m.scattering_tex, texcoord, true);
@@ -375,6 +373,31 @@ VPT_DEV mpoint eval_material(const DScene& sc, const DInstance& inst, int elemen
   p.scanisotropy = m.scanisotropy;
   finish_material(p, m.trdepth);
   return p;
+}
+VPT_DEV mpoint eval_material(const DScene& sc, const DInstance& inst, int element, f2 uv) {
+  return eval_material_at(sc, sc.materials[inst.material], eval_texcoord(sc, inst, element, uv), eval_color(sc, inst, element, uv));
+}
+// eval_position + eval_normal + eval_texcoord (yocto_scene.cpp:279-379) of a hit from its primitive slot: the same
+// corner choice (pick_corners), the same interpolation, the same values - fetched from leaf_prims / leaf_attrs.
+// Only for shapes with vertex normals and without vertex colours (the callers check shape_flags).
+VPT_DEV void eval_surface_slot(const DScene& sc, const DInstance& inst, int prim, f2 uv, f3& position, f3& normal, f2& texcoord) {
+  int a, b, c;
+  f2  w = uv;
+  if (inst.shape_flags & VPT_SHP_TRIANGLES) a = 0, b = 1, c = 2;
+  else if (uv.x + uv.y <= 1) a = 0, b = 1, c = 3;
+  else a = 2, b = 3, c = 1, w = 1 - uv;
+  const float4* P = sc.leaf_prims + 4 * (long long)prim;
+  const float4* A = sc.leaf_attrs + 6 * (long long)prim;
+  float4 pa = P[a], pb = P[b], pc = P[c], na = A[a], nb = A[b], nc = A[c];
+  frame  f = unpack_frame(inst.fwd[0], inst.fwd[1], inst.fwd[2]);
+  position = transform_point(f, tri_lerp(xyz(pa), xyz(pb), xyz(pc), w));
+  normal   = transform_direction(f, normalize(tri_lerp(xyz(na), xyz(nb), xyz(nc), w)));
+  texcoord = uv;
+  if (inst.shape_flags & VPT_SHP_TEXCOORDS) {
+    const float2* T = (const float2*)(A + 4);
+    float2 ta = T[a], tb = T[b], tc = T[c];
+    texcoord = tri_lerp(mk2(ta.x, ta.y), mk2(tb.x, tb.y), mk2(tc.x, tc.y), w);
+  }
 }
 VPT_DEV mpoint eval_material_plain(const DScene& sc, int mat) {   // yocto_scene.cpp:581-619
   const vpt_material& m = sc.materials[mat];

@@ -221,18 +221,22 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
       for (int s = 0; s < sc.num_scene_prims; s++) {
         const float4* e = sc.scene_enter + 6 * s;
         float4 e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5];
-        f3   lo, linv;
-        bool lslow;
-        if (!__float_as_int(e5.z) || any_slow) {
-          frame inv = unpack_frame(e[0], e[1], e2);
-          f3    ld  = transform_vector(inv, wd);
-          lo = transform_point(inv, wo), linv = rcp3_exact(ld), lslow = nan_prone(ld, linv);
-        } else {
-          lo = mk3(wo.x + e2.y, wo.y + e2.z, wo.z + e2.w), linv = winv, lslow = false;
-        }
+        // the record is the same for every lane: branch on its flags as scalars, each arm complete in itself
+        int  translation = __builtin_amdgcn_readfirstlane(__float_as_int(e5.z));
+        int  has_root    = __builtin_amdgcn_readfirstlane(__float_as_int(e5.w));
+        if (!has_root) continue;
+        f3    blo = mk3(e3.x, e3.y, e3.z), bhi = mk3(e3.w, e4.x, e4.y);
         float t0;
-        if (__float_as_int(e5.w) && box_test(lslow, mk3(e3.x, e3.y, e3.z), mk3(e3.w, e4.x, e4.y), lo, linv, tmin, VPT_FLT_MAX, t0))
-          reach |= 1u << s;
+        bool  pass;
+        if (translation && !any_slow) {
+          pass = box_pass_fast(blo, bhi, mk3(wo.x + e2.y, wo.y + e2.z, wo.z + e2.w), winv, tmin, VPT_FLT_MAX, t0);
+        } else {
+          frame inv  = unpack_frame(e[0], e[1], e2);
+          f3    ld   = transform_vector(inv, wd);
+          f3    linv = rcp3_exact(ld);
+          pass = box_test(nan_prone(ld, linv), blo, bhi, transform_point(inv, wo), linv, tmin, VPT_FLT_MAX, t0);
+        }
+        if (pass) reach |= 1u << s;
       }
     }
   } else {   // single-instance query (yocto_bvh.cpp:874-881)

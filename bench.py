@@ -154,7 +154,11 @@ def main():
         # memory-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
         # runs of this same command); only quoted for the workload it was measured on
         traffic = None
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))   # latest round's passes
+        def _version(path):   # profiles/r<round>_v<version>_hbm_traffic.json, compared numerically
+            import re
+            m = re.search(r"r(\d+)_v(\d+)_", os.path.basename(path))
+            return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), key=_version)   # latest passes
         tfile = tfiles[-1] if tfiles else ""
         if tfile and args.scene == SCENE and args.shader == "volpathtrace" and args.bounces == 64:
             traffic = round(json.load(open(tfile))["bytes_per_sample"] * per_launch_samples)

@@ -895,7 +895,9 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
       long long key_[10] = {pr.nslots, pr.width, pr.height, params->shader, params->camera, params->bounces,      \
                             pr.rank, pr.nranks, pr.tile_w, pr.tile_h};                                            \
       if (int rc_ = sched_prepare(s, grid.x, key_, st)) return rc_;                                             \
-      int parts_[2] = {(!s->order_valid && pr.nsamples >= 16) ? 1 : pr.nsamples, 0};                            \
+      /* pilot: 1/64 of the call's samples, 1..16 (a one-sample estimate costs the ordered launch ~7 %) */    \
+      int pilot_n_ = pr.nsamples / 64 < 1 ? 1 : pr.nsamples / 64 > 16 ? 16 : pr.nsamples / 64;                    \
+      int parts_[2] = {(!s->order_valid && pr.nsamples >= 16) ? pilot_n_ : pr.nsamples, 0};                     \
       parts_[1] = pr.nsamples - parts_[0];                                                                       \
       for (int part_ = 0; part_ < 2 && parts_[part_] > 0; part_++) {                                            \
         DParams   prp_ = pr;                                                                                     \

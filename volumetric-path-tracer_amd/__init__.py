@@ -161,9 +161,9 @@ class HostScene:
         return st
 
     def close(self) -> None:
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and host is not None:   # at interpreter shutdown the module globals may be gone
             host.vpth_scene_free(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         self.close()
@@ -208,9 +208,9 @@ class DeviceScene:
         return ms.value
 
     def close(self) -> None:
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and hip is not None:   # see HostScene.close
             hip.vpt_scene_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         self.close()

@@ -273,6 +273,13 @@ int vpt_render_device(vpt_scene* scene, const vpt_params* params, const vpt_layo
 int vpt_resolve_device(const vpt_layout* layout, const void* d_tiles_all_ranks, int samples,
                        void* d_image_rowmajor, void* stream);
 
+/* the same followed by the 8-bit output stage of save_image (rgb_to_srgb + float_to_byte, yocto_color.h:207-231;
+ * yocto_sceneio.cpp:509-571 then hands the bytes to the encoder): row-major RGBA8 on the device, 4 B per pixel
+ * to download for a preview instead of 16.  Uses the device's powf: a byte may differ by one from the host
+ * routine where the curve lands within an ulp of a quantisation step (parity checks use the host routine). */
+int vpt_resolve_srgb8_device(const vpt_layout* layout, const void* d_tiles_all_ranks, int samples,
+                             void* d_rgba8_rowmajor, void* stream);
+
 /* per-launch profile of the last vpt_render_device on this scene (HIP events on `stream`) */
 int vpt_last_kernel_ms(vpt_scene* scene, float* ms);
 

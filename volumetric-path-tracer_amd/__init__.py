@@ -100,6 +100,7 @@ hip.vpt_state_download.argtypes = [C.POINTER(VptLayout), _p, _p, _p, _p, _p, _p,
 hip.vpt_render_device.argtypes = [_p, C.POINTER(VptParams), C.POINTER(VptLayout), C.c_int, _p, _p, _p, _p]
 hip.vpt_resolve_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
 hip.vpt_last_kernel_ms.argtypes = [_p, C.POINTER(C.c_float)]
+hip.vpt_resolve_srgb8_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
 hip.vpt_selftest_reciprocal.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
 hip.vpt_selftest_light_cdf.argtypes = [_p, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
 host.vpth_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
@@ -235,6 +236,11 @@ def state_download(layout: VptLayout, d_image: int, d_hits: int, d_rng: int, sta
 
 def resolve_device(layout: VptLayout, d_tiles_all: int, samples: int, d_rows: int, stream: int = 0):
     _check(hip.vpt_resolve_device(C.byref(layout), d_tiles_all, samples, d_rows, stream), "vpt_resolve_device")
+
+
+def resolve_srgb8_device(layout: VptLayout, d_tiles_all: int, samples: int, d_rgba8: int, stream: int = 0):
+    """get_render + rgb_to_srgb + float_to_byte on the device (row-major RGBA8)"""
+    _check(hip.vpt_resolve_srgb8_device(C.byref(layout), d_tiles_all, samples, d_rgba8, stream), "vpt_resolve_srgb8_device")
 
 
 def get_render(state: PathtraceState) -> np.ndarray:

@@ -953,6 +953,20 @@ int vpt_resolve_device(const vpt_layout* layout, const void* d_tiles_all_ranks, 
   return VPT_OK;
 }
 
+int vpt_resolve_srgb8_device(const vpt_layout* layout, const void* d_tiles_all_ranks, int samples, void* d_rgba8_rowmajor, void* stream) {
+  if (!layout || !d_tiles_all_ranks || !d_rgba8_rowmajor || samples <= 0) return fail(VPT_ERR_INVALID_ARG, "bad argument");
+  DParams    pr;
+  vpt_params dummy = {};
+  if (int rc = make_dparams(&dummy, layout, 0, pr)) return rc;
+  long long total = (long long)pr.nslots * pr.nranks;
+  if (total >= (1LL << 31)) return fail(VPT_ERR_INVALID_ARG, "image too large");
+  int blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(vpt_resolve_srgb8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pr, (const float4*)d_tiles_all_ranks,
+      1.0f / (float)samples, (uchar4*)d_rgba8_rowmajor);
+  HIP_TRY(hipGetLastError());
+  return VPT_OK;
+}
+
 int vpt_render(vpt_scene* s, const vpt_params* params, int nsamples, int width, int height, float* image_rgba,
     int32_t* hits, uint64_t* rng, int* samples_io) {
   if (!s || !params || !image_rgba || !hits || !rng || !samples_io) return fail(VPT_ERR_INVALID_ARG, "null argument");

@@ -346,3 +346,25 @@ __global__ void vpt_resolve_kernel(DParams pr, const float4* tiles_all, float sc
   float4 v = tiles_all[g];
   rows_image[(long long)py * pr.width + px] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
 }
+
+// The output stage of a preview on the device: get_render (cpp:1105-1116) followed by rgb_to_srgb
+// (yocto_color.h:228-231) and float_to_byte (:207-211, clamp(int(a * 256), 0, 255)); alpha is quantised
+// linearly, as save_image does.  powf is ocml's here and glibc's in the reference: a byte can differ by one
+// where the curve lands within an ulp of a multiple of 1/256 (the parity pipeline keeps using the host
+// routine, vpth_linear_to_srgb8).
+__global__ void vpt_resolve_srgb8_kernel(DParams pr, const float4* tiles_all, float scale, uchar4* rows_rgba8) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;   // global slot over all ranks
+  if (g >= pr.nslots * pr.nranks) return;
+  DParams q = pr;
+  q.rank    = g / pr.nslots;
+  int px, py;
+  if (!slot_to_pixel(q, g - q.rank * pr.nslots, px, py)) return;
+  float4 v = tiles_all[g];
+  auto curve = [](float rgb) { return (rgb <= 0.0031308f) ? 12.92f * rgb : (1 + 0.055f) * powf(rgb, 1 / 2.4f) - 0.055f; };
+  auto quant = [](float a) {
+    int b = (int)(a * 256);
+    return (unsigned char)(b < 0 ? 0 : (b > 255 ? 255 : b));
+  };
+  rows_rgba8[(long long)py * pr.width + px] =
+      make_uchar4(quant(curve(v.x * scale)), quant(curve(v.y * scale)), quant(curve(v.z * scale)), quant(v.w * scale));
+}

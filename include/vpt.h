@@ -283,6 +283,13 @@ int vpt_resolve_srgb8_device(const vpt_layout* layout, const void* d_tiles_all_r
 /* per-launch profile of the last vpt_render_device on this scene (HIP events on `stream`) */
 int vpt_last_kernel_ms(vpt_scene* scene, float* ms);
 
+/* intersect_bvh(bvh, scene, ray) (instance < 0) / intersect_bvh(bvh, scene, instance, ray) of yocto_bvh.h, for a
+ * batch of `n` host rays {o.xyz, d.xyz} with the reference's default tmin = 1e-4, tmax = flt_max, through the
+ * kernels' own traversal.  ids[2i..] = {instance, element} (-1, -1 on a miss), uvt[3i..] = {u, v, distance}.
+ * Synchronous.  The parity tests use it to compare the traversal with the reference's bit for bit on rays path
+ * tracing rarely produces (axis-aligned, grazing a box plane, denormal direction components). */
+int vpt_intersect(vpt_scene* scene, int n, const float* rays, int instance, int32_t* ids, float* uvt);
+
 /* Device self-test of an arithmetic shortcut the kernels rely on for bit-exact parity: the reference divides
  * (1 / d per ray, yocto_bvh.cpp:806-808; 1 / det per triangle, yocto_geometry.h:690), the kernels use
  * v_rcp_f32 + one Newton step where every lane's operand has a biased exponent in 1..250.  Runs all 2^32 bit

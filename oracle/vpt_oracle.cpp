@@ -1610,6 +1610,21 @@ extern "C" int vpt_oracle_render(const vpt_scene_desc* desc, const vpt_params* p
   return VPT_OK;
 }
 
+// intersect_bvh(bvh, scene, ray) / intersect_bvh(bvh, scene, instance, ray) (yocto_bvh.cpp:1097-1113) for a batch
+// of rays {o, d} with the default tmin = 1e-4, tmax = flt_max: the checker for vpt_intersect (include/vpt.h).
+// ids: {instance, element} per ray (-1, -1 on a miss); uvt: {u, v, distance} (zeros on a miss).
+extern "C" int vpt_oracle_intersect(const vpt_scene_desc* desc, int n, const float* rays, int instance, int32_t* ids, float* uvt) {
+  if (!desc || !rays || !ids || !uvt || n < 0) return VPT_ERR_INVALID_ARG;
+  if (instance >= desc->num_instances) return VPT_ERR_INVALID_ARG;
+  for (auto i = 0; i < n; i++) {
+    auto ray = make_ray({rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, {rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]});
+    auto r   = instance < 0 ? intersect_scene_bvh(*desc, ray) : intersect_instance_bvh(*desc, instance, ray);
+    ids[2 * i] = r.hit ? r.instance : -1, ids[2 * i + 1] = r.hit ? r.element : -1;
+    uvt[3 * i] = r.hit ? r.uv.x : 0, uvt[3 * i + 1] = r.hit ? r.uv.y : 0, uvt[3 * i + 2] = r.hit ? r.distance : 0;
+  }
+  return VPT_OK;
+}
+
 extern "C" const char* vpt_oracle_counter_names() {
   return "samples,scene_nodes,shape_nodes,instance_tests,quad_tests,tri_tests,texel_f32,texel_u8,cdf_probes,"
          "surface_hits,volume_events,bounces,sdf_evals,voxel_fetches,light_pdf_hops";

@@ -44,6 +44,18 @@ def oracle_render(host_scene, params, state, nsamples, nthreads=0, counters=Fals
     return dict(zip(COUNTER_NAMES, (int(x) for x in cnt))) if counters else None
 
 
+def oracle_intersect(host_scene, rays, instance=-1):
+    """The oracle's intersect_bvh for an (n, 6) float32 array of rays: (ids (n, 2) int32, uvt (n, 3) float32)."""
+    rays = np.ascontiguousarray(rays, np.float32)
+    n = rays.shape[0]
+    ids, uvt = np.zeros((n, 2), np.int32), np.zeros((n, 3), np.float32)
+    lib().vpt_oracle_intersect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rc = lib().vpt_oracle_intersect(host_scene.desc, n, rays.ctypes.data, instance, ids.ctypes.data, uvt.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle intersect failed: {rc}")
+    return ids, uvt
+
+
 def have_reference():
     return os.path.exists(REF_DRIVER)
 

@@ -312,3 +312,49 @@ def test_device_output_stage_matches_host_quantisation(vpt, scene03, dev03):
     diff = np.abs(got - ref)
     assert diff.max() <= 1
     assert (diff != 0).mean() < 1e-3
+
+
+def _edge_rays(rng, lo, hi, n):
+    """Rays path tracing rarely produces: axis-aligned and one-zero-component directions, origins on the
+    coordinate planes box faces tend to lie on (0*inf in the slab test), denormal direction components."""
+    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    kind = np.arange(n) % 8
+    axis = rng.integers(0, 3, size=n)
+    sign = rng.choice(np.float32([-1, 1]), size=n)
+    for i in range(n):
+        k, a = kind[i], axis[i]
+        if k == 1:      # axis-aligned direction
+            d[i] = 0
+            d[i, a] = sign[i]
+        elif k == 2:    # one zero component
+            d[i, a] = 0
+        elif k == 3:    # zero component and the origin on that coordinate plane (grazes box faces at 0)
+            d[i, a] = 0
+            o[i, a] = 0
+        elif k == 4:    # denormal component: 1/d overflows
+            d[i, a] = np.float32(1e-40) * sign[i]
+        elif k == 5:    # tiny but normal component
+            d[i, a] = np.float32(1e-30) * sign[i]
+        elif k == 6:    # origin on a plane, direction not in it
+            o[i, a] = 0
+    return np.concatenate([o, d], axis=1)
+
+
+@pytest.mark.parametrize("scene_file,lo,hi", [
+    ("03_volume/volume.json", (-0.7, -0.05, -0.45), (0.7, 0.45, 0.45)),
+    ("05_head1ss_sub/head1ss_sub.json", (-0.25, -0.1, -0.25), (0.25, 0.4, 0.25)),
+])
+def test_intersect_is_bit_identical_on_edge_case_rays(vpt, oracle, scene_file, lo, hi):
+    """vpt_intersect (the kernels' quad-node traversal) against the oracle's intersect_bvh, ray by ray: instance,
+    element, uv and distance must agree bit for bit, also for NaN-prone rays and for single-instance queries."""
+    scene = vpt.HostScene(os.path.join(GOLDEN, "scenes", scene_file))
+    dev = vpt.DeviceScene(scene, 0)
+    rays = _edge_rays(np.random.default_rng(7), lo, hi, 40000)
+    for instance in (-1, 0):
+        ids, uvt = dev.intersect(rays, instance)
+        rids, ruvt = oracle.oracle_intersect(scene, rays, instance)
+        assert (ids[:, 0] >= 0).mean() > 0.05   # the batch does hit things
+        assert np.array_equal(ids, rids), np.nonzero((ids != rids).any(axis=1))[0][:10]
+        assert np.array_equal(uvt.view(np.uint32), ruvt.view(np.uint32)), np.nonzero((uvt.view(np.uint32) != ruvt.view(np.uint32)).any(axis=1))[0][:10]

@@ -100,6 +100,7 @@ hip.vpt_state_download.argtypes = [C.POINTER(VptLayout), _p, _p, _p, _p, _p, _p,
 hip.vpt_render_device.argtypes = [_p, C.POINTER(VptParams), C.POINTER(VptLayout), C.c_int, _p, _p, _p, _p]
 hip.vpt_resolve_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
 hip.vpt_last_kernel_ms.argtypes = [_p, C.POINTER(C.c_float)]
+hip.vpt_intersect.argtypes = [_p, C.c_int, _p, C.c_int, _p, _p]
 hip.vpt_resolve_srgb8_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
 hip.vpt_selftest_reciprocal.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
 hip.vpt_selftest_light_cdf.argtypes = [_p, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
@@ -196,6 +197,14 @@ class DeviceScene:
         abi = params.to_abi()
         _check(hip.vpt_render_device(self.handle, C.byref(abi), C.byref(layout), nsamples, d_image, d_hits, d_rng,
                                      stream), "vpt_render_device")
+
+    def intersect(self, rays: np.ndarray, instance: int = -1):
+        """intersect_bvh for an (n, 6) float32 array of rays {o, d}: returns (ids (n, 2) int32, uvt (n, 3) float32)"""
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = rays.shape[0]
+        ids, uvt = np.zeros((n, 2), np.int32), np.zeros((n, 3), np.float32)
+        _check(hip.vpt_intersect(self.handle, n, rays.ctypes.data, instance, ids.ctypes.data, uvt.ctypes.data), "vpt_intersect")
+        return ids, uvt
 
     def selftest_light_cdf(self, light: int, n: int = 1 << 20):
         """(mismatches, indexed) of the light-CDF search structure against the plain binary search (include/vpt.h)"""

@@ -62,6 +62,19 @@ __global__ void vpt_light_cdf_selftest_kernel(DScene sc, int light_id, int n, un
   if (live && a != b) atomicAdd(&out[0], 1ull);
 }
 
+// vpt_intersect: one lane per ray through the production traversal
+template <bool SPILL>
+__global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_intersect_kernel(DScene sc, int n, const float* rays, int instance,
+    int* ids, float* uvt, stack_cfg stack) {
+  extern __shared__ int lds_stack[];
+  const lane_stack2<SPILL> stk = make_lane_stack<SPILL>(lds_stack, stack);
+  int i = blockIdx.x * VPT_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  hit_t h = traverse(sc, mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]), instance, stk);
+  ids[2 * i] = h.hit ? h.instance : -1, ids[2 * i + 1] = h.hit ? h.element : -1;
+  uvt[3 * i] = h.hit ? h.uv.x : 0, uvt[3 * i + 1] = h.hit ? h.uv.y : 0, uvt[3 * i + 2] = h.hit ? h.distance : 0;
+}
+
 // all 2^32 operands of rcp_newton (vpt_mesh_kernel.hip.h) against the IEEE quotient; out[0] = mismatches, out[1] = out of range
 __global__ void vpt_reciprocal_selftest_kernel(unsigned long long* out) {
   unsigned long long bad = 0, skipped = 0;
@@ -1006,6 +1019,31 @@ int vpt_selftest_reciprocal(int device, unsigned long long* mismatches, unsigned
   (void)hipFree(d);
   *mismatches = h[0], *fallbacks = h[1];
   return rc;
+}
+
+int vpt_intersect(vpt_scene* s, int n, const float* rays, int instance, int32_t* ids, float* uvt) {
+  if (!s || !rays || !ids || !uvt || n < 0) return fail(VPT_ERR_INVALID_ARG, "bad argument");
+  if (instance >= s->d.num_instances) return fail(VPT_ERR_INVALID_ARG, "instance %d out of range", instance);
+  if (n == 0) return VPT_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  float* d_rays = nullptr;
+  int*   d_ids  = nullptr;
+  float* d_uvt  = nullptr;
+  auto   release = [&] { (void)hipFree(d_rays), (void)hipFree(d_ids), (void)hipFree(d_uvt); };
+  if (hipMalloc((void**)&d_rays, (size_t)n * 24) != hipSuccess || hipMalloc((void**)&d_ids, (size_t)n * 8) != hipSuccess ||
+      hipMalloc((void**)&d_uvt, (size_t)n * 12) != hipSuccess || hipMemcpy(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice) != hipSuccess) {
+    release();
+    return fail(VPT_ERR_HIP, "vpt_intersect: device buffers");
+  }
+  int       blocks = (n + VPT_BLOCK - 1) / VPT_BLOCK;
+  stack_cfg stack;
+  if (int rc = stack_config(s, (long long)blocks * VPT_BLOCK, stack)) { release(); return rc; }
+  size_t lds = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int);
+  if (stack.spill) hipLaunchKernelGGL(vpt_intersect_kernel<true>, dim3(blocks), dim3(VPT_BLOCK), lds, 0, s->d, n, d_rays, instance, d_ids, d_uvt, stack);
+  else hipLaunchKernelGGL(vpt_intersect_kernel<false>, dim3(blocks), dim3(VPT_BLOCK), lds, 0, s->d, n, d_rays, instance, d_ids, d_uvt, stack);
+  bool ok = hipMemcpy(ids, d_ids, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(uvt, d_uvt, (size_t)n * 12, hipMemcpyDeviceToHost) == hipSuccess;
+  release();
+  return ok ? VPT_OK : fail(VPT_ERR_HIP, "vpt_intersect failed to run");
 }
 
 int vpt_selftest_light_cdf(vpt_scene* s, int light, int n, unsigned long long* mismatches, int* indexed) {

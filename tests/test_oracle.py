@@ -130,3 +130,37 @@ def test_host_pipeline_matches_reference_on_substitute_scenes(vpt):
         assert mine == stats, scene_file
     assert golden["05_head1ss_sub/head1ss_sub.json"]["shapes"][0]["triangles"] == 144046
     assert golden["06_gridsdf_synth/gridsdf_synth.json"]["volumes"][0]["whd"] == [48, 48, 48]
+
+
+def test_oracle_intersect_reproduces_the_references_primary_ray_hits(vpt, oracle):
+    """SURVEY.md §8(c) KAT (3), measured on the reference: hits of eval_camera(cam, {u, 0.6}, {.5, .5}) on
+    03_volume.  The rays are rebuilt here in float32 with eval_camera's operation order (yocto_scene.cpp:67-102);
+    instance, element and the float32 distance (for the first ray also uv) must match exactly."""
+    import json
+    f32 = np.float32
+    scene_file = os.path.join(GOLDEN, "scenes", "03_volume", "volume.json")
+    cam = json.load(open(scene_file))["cameras"][0]
+    fr = [f32(x) for x in cam["frame"]]
+    fx, fy, fz, fo = fr[0:3], fr[3:6], fr[6:9], fr[9:12]
+    lens, aspect, film, focus = f32(cam["lens"]), f32(cam["aspect"]), f32(0.036), f32(10000)
+    film_x, film_y = film, film / aspect
+
+    def normalize(v):
+        l = np.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+        return [v[0] / l, v[1] / l, v[2] / l]
+
+    rays = []
+    for u in (0.125, 0.375, 0.625, 0.875):
+        q = [film_x * (f32(0.5) - f32(u)), film_y * (f32(0.6) - f32(0.5)), lens]
+        dc = [-c for c in normalize(q)]
+        p = [c * focus / abs(dc[2]) for c in dc]
+        d = normalize(p)   # aperture 0: e = 0
+        w = normalize([fx[k] * d[0] + fy[k] * d[1] + fz[k] * d[2] for k in range(3)])
+        rays.append([fo[0], fo[1], fo[2], w[0], w[1], w[2]])
+    scene = vpt.HostScene(scene_file)
+    ids, uvt = oracle.oracle_intersect(scene, np.array(rays, np.float32))
+    expect = [(1, 3967, "0x1.e6df4ap-1"), (4, 3581, "0x1.098388p+0"), (2, 105, "0x1.2cc07cp+0"), (0, 0, "0x1.4f6724p+0")]
+    for k, (inst, elem, t) in enumerate(expect):
+        assert (int(ids[k, 0]), int(ids[k, 1])) == (inst, elem)
+        assert float(uvt[k, 2]) == float.fromhex(t)
+    assert (float(uvt[0, 0]), float(uvt[0, 1])) == (float.fromhex("0x1.539538p-1"), float.fromhex("0x1.5c8288p-1"))

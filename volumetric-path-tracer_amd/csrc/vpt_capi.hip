@@ -867,6 +867,64 @@ static bool use_stream_pipeline() {
   return choice != 0;
 }
 
+// everything one vpt_render_device call hands to the kernel launchers
+struct launch_ctx {
+  vpt_scene*        s;
+  const vpt_params* params;
+  const DParams&    pr;
+  dim3              grid, block;
+  hipStream_t       st;
+  float4*           img;
+  int*              hit;
+  ulonglong2*       rng;
+  stack_cfg         stack;
+};
+static void schedule_key(const launch_ctx& L, long long key[10]) {
+  const DParams& pr = L.pr;
+  long long k[10] = {pr.nslots, pr.width, pr.height, L.params->shader, L.params->camera, L.params->bounces, pr.rank, pr.nranks, pr.tile_w, pr.tile_h};
+  memcpy(key, k, sizeof(k));
+}
+
+// K1 (mesh shaders).  Longest-wave-first order from the costs of the previous launch on this layout; without
+// them a pilot launch over 1/64 of the call's samples (1..16) measures them first - same arithmetic, batching is exact.
+template <int K>
+static int launch_mesh(const launch_ctx& L) {
+  vpt_scene* s = L.s;
+  if (use_stream_pipeline()) return render_stream<K>(s, L.pr, L.img, L.hit, L.rng, L.st);
+  long long key[10];
+  schedule_key(L, key);
+  if (int rc = sched_prepare(s, L.grid.x, key, L.st)) return rc;
+  size_t lds = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int);   // (ref, t0) pairs
+  int n = L.pr.nsamples, pilot = n / 64 < 1 ? 1 : n / 64 > 16 ? 16 : n / 64;
+  int parts[2] = {(!s->order_valid && n >= 16) ? pilot : n, 0};
+  parts[1] = n - parts[0];
+  for (int part = 0; part < 2 && parts[part] > 0; part++) {
+    DParams pr  = L.pr;
+    pr.nsamples = parts[part];
+    sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost};
+    bool is_pilot = parts[1] > 0 && part == 0;
+    if (is_pilot && L.stack.spill) hipLaunchKernelGGL((vpt_mesh_pilot_kernel<K, true>), L.grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
+    else if (is_pilot) hipLaunchKernelGGL((vpt_mesh_pilot_kernel<K, false>), L.grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
+    else if (L.stack.spill) hipLaunchKernelGGL((vpt_mesh_kernel<K, true>), L.grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
+    else hipLaunchKernelGGL((vpt_mesh_kernel<K, false>), L.grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
+    if (int rc = sched_update(s, L.grid.x, L.st)) return rc;
+  }
+  return VPT_OK;
+}
+// K2 (implicit shaders): same schedule, costs from the previous launch on this layout (no pilot)
+template <int K>
+static int launch_implicit(const launch_ctx& L) {
+  vpt_scene* s = L.s;
+  long long key[10];
+  schedule_key(L, key);
+  if (int rc = sched_prepare(s, L.grid.x, key, L.st)) return rc;
+  size_t    lds = (size_t)s->stack_cap * VPT_BLOCK * sizeof(int);   // refs only
+  sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost};
+  hipLaunchKernelGGL(vpt_render_kernel<K>, L.grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch);
+  return sched_update(s, L.grid.x, L.st);
+}
+
+
 extern "C" {
 
 int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* layout, int nsamples, void* d_image,
@@ -881,63 +939,26 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
   dim3   grid((pr.nslots + VPT_BLOCK - 1) / VPT_BLOCK), block(VPT_BLOCK);
-  size_t lds  = (size_t)s->stack_cap * VPT_BLOCK * sizeof(int);       // implicit kernels: refs only
-  size_t lds2 = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int);   // mesh kernel: (ref, t0) pairs
   stack_cfg stack;
   if (int rc = stack_config(s, (long long)grid.x * VPT_BLOCK, stack)) return rc;
   auto   img = (float4*)d_image;
   auto   hit = (int*)d_hits;
   auto   rng = (ulonglong2*)d_rng;
   HIP_TRY(hipEventRecord(s->ev0, st));
-  /* implicit shaders: same longest-first schedule, costs from the previous launch on this layout (no pilot) */
-#define LAUNCH(K)                                                                                                \
-  do {                                                                                                          \
-    long long key_[10] = {pr.nslots, pr.width, pr.height, params->shader, params->camera, params->bounces,      \
-                          pr.rank, pr.nranks, pr.tile_w, pr.tile_h};                                            \
-    if (int rc_ = sched_prepare(s, grid.x, key_, st)) return rc_;                                               \
-    sched_cfg sch_ = {s->order_valid ? s->d_order : nullptr, s->d_cost};                                       \
-    hipLaunchKernelGGL(vpt_render_kernel<K>, grid, block, lds, st, s->d, pr, img, hit, rng, s->stack_cap, sch_); \
-    if (int rc_ = sched_update(s, grid.x, st)) return rc_;                                                      \
-  } while (0)
-#define LAUNCH_MESH(K)                                                                                          \
-  do {                                                                                                          \
-    if (use_stream_pipeline()) {                                                                                \
-      if (int rc_ = render_stream<K>(s, pr, img, hit, rng, st)) return rc_;                                     \
-    } else {                                                                                                    \
-      /* without measured costs, a one-sample pilot launch (same arithmetic: batching is exact) provides them */ \
-      long long key_[10] = {pr.nslots, pr.width, pr.height, params->shader, params->camera, params->bounces,      \
-                            pr.rank, pr.nranks, pr.tile_w, pr.tile_h};                                            \
-      if (int rc_ = sched_prepare(s, grid.x, key_, st)) return rc_;                                             \
-      /* pilot: 1/64 of the call's samples, 1..16 (a one-sample estimate costs the ordered launch ~7 %) */    \
-      int pilot_n_ = pr.nsamples / 64 < 1 ? 1 : pr.nsamples / 64 > 16 ? 16 : pr.nsamples / 64;                    \
-      int parts_[2] = {(!s->order_valid && pr.nsamples >= 16) ? pilot_n_ : pr.nsamples, 0};                     \
-      parts_[1] = pr.nsamples - parts_[0];                                                                       \
-      for (int part_ = 0; part_ < 2 && parts_[part_] > 0; part_++) {                                            \
-        DParams   prp_ = pr;                                                                                     \
-        prp_.nsamples  = parts_[part_];                                                                          \
-        sched_cfg sch_ = {s->order_valid ? s->d_order : nullptr, s->d_cost};                                     \
-        bool pilot_ = parts_[1] > 0 && part_ == 0;                                                               \
-        if (pilot_ && stack.spill) hipLaunchKernelGGL((vpt_mesh_pilot_kernel<K, true>), grid, block, lds2, st, s->d, prp_, img, hit, rng, stack, sch_);   \
-        else if (pilot_) hipLaunchKernelGGL((vpt_mesh_pilot_kernel<K, false>), grid, block, lds2, st, s->d, prp_, img, hit, rng, stack, sch_);            \
-        else if (stack.spill) hipLaunchKernelGGL((vpt_mesh_kernel<K, true>), grid, block, lds2, st, s->d, prp_, img, hit, rng, stack, sch_);              \
-        else hipLaunchKernelGGL((vpt_mesh_kernel<K, false>), grid, block, lds2, st, s->d, prp_, img, hit, rng, stack, sch_);                              \
-        if (int rc_ = sched_update(s, grid.x, st)) return rc_;                                                  \
-      }                                                                                                         \
-    }                                                                                                           \
-  } while (0)
+  launch_ctx L = {s, params, pr, grid, block, st, img, hit, rng, stack};
+  int rc = VPT_OK;
   switch (params->shader) {
-    case VPT_SHADER_VOLPATHTRACE: LAUNCH_MESH(K_VOLPATH); break;
-    case VPT_SHADER_PATHTRACE: LAUNCH_MESH(K_PATH); break;
-    case VPT_SHADER_NAIVE: LAUNCH_MESH(K_NAIVE); break;
-    case VPT_SHADER_EYELIGHT: LAUNCH_MESH(K_EYELIGHT); break;
+    case VPT_SHADER_VOLPATHTRACE: rc = launch_mesh<K_VOLPATH>(L); break;
+    case VPT_SHADER_PATHTRACE: rc = launch_mesh<K_PATH>(L); break;
+    case VPT_SHADER_NAIVE: rc = launch_mesh<K_NAIVE>(L); break;
+    case VPT_SHADER_EYELIGHT: rc = launch_mesh<K_EYELIGHT>(L); break;
     case VPT_SHADER_NORMAL:
     case VPT_SHADER_TEXCOORD:
-    case VPT_SHADER_COLOR: LAUNCH_MESH(K_DEBUG); break;
-    case VPT_SHADER_IMPLICIT: LAUNCH(K_IMPLICIT); break;
-    case VPT_SHADER_IMPLICIT_NORMAL: LAUNCH(K_IMPLICIT_NORMAL); break;
+    case VPT_SHADER_COLOR: rc = launch_mesh<K_DEBUG>(L); break;
+    case VPT_SHADER_IMPLICIT: rc = launch_implicit<K_IMPLICIT>(L); break;
+    case VPT_SHADER_IMPLICIT_NORMAL: rc = launch_implicit<K_IMPLICIT_NORMAL>(L); break;
   }
-#undef LAUNCH
-#undef LAUNCH_MESH
+  if (rc != VPT_OK) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev1, st));
   s->timed = true;

@@ -54,9 +54,6 @@ const vpt_scene_desc* vpth_scene_desc(void* h) { return &((host_scene*)h)->flat.
 int vpth_state_size(void* h, int camera, int resolution, int* width, int* height) {
   auto& scene = ((host_scene*)h)->scene;
   if (camera < 0 || camera >= (int)scene.cameras.size()) return -1;
-  auto params       = pathtrace_params{};
-  params.camera     = camera;
-  params.resolution = resolution;
   auto aspect       = scene.cameras[camera].aspect;
   if (aspect >= 1) *width = resolution, *height = (int)std::round(resolution / aspect);
   else *height = resolution, *width = (int)std::round(resolution * aspect);
@@ -66,6 +63,7 @@ int vpth_state_size(void* h, int camera, int resolution, int* width, int* height
 int vpth_make_state(void* h, int camera, int resolution, float* image, int32_t* hits, uint64_t* rng) {
   try {
     auto params       = pathtrace_params{};
+  (void)params;
     params.camera     = camera;
     params.resolution = resolution;
     auto state        = make_state(((host_scene*)h)->scene, params);

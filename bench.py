@@ -39,13 +39,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 def algorithmic_bytes_per_sample(c):
     """B = 32*(scene+shape nodes) + 64*instance tests + 4*(instance+prim tests)
-    + P*prim tests + 16*f32 texels + 4*u8 texels + 4*cdf probes + V*surface hits + 72."""
+    + P*prim tests + 16*f32 texels + 4*u8 texels + 4*cdf probes + V*surface hits + 72, plus 4 B per voxel the
+    trilinear SDF lookup fetches (the implicit shaders' only per-lane gather).  Analytic SDF evaluations read
+    wave-uniform records (scalar loads) and are charged nothing."""
     n = float(c["samples"])
     prim = c["quad_tests"] + c["tri_tests"]
     b = (32.0 * (c["scene_nodes"] + c["shape_nodes"]) + 64.0 * c["instance_tests"]
          + 4.0 * (c["instance_tests"] + prim) + 64.0 * c["quad_tests"] + 48.0 * c["tri_tests"]
          + 16.0 * c["texel_f32"] + 4.0 * c["texel_u8"] + 4.0 * c["cdf_probes"] + 80.0 * c["surface_hits"]
-         + 4.0 * c["voxel_fetches"] + 64.0 * c["sdf_evals"]) / n + 72.0
+         + 4.0 * c["voxel_fetches"]) / n + 72.0
     return b
 
 

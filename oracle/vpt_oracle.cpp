@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "vpt.h"
+#include "vpt_kat.h"
 
 namespace {
 
@@ -147,6 +148,13 @@ enum { C_SAMPLES, C_SCENE_NODES, C_SHAPE_NODES, C_INSTANCE_TESTS, C_QUAD_TESTS, 
   C_VOXEL_FETCHES, C_LIGHT_PDF_HOPS, C_COUNT = 16 };
 thread_local uint64_t tl_counters[C_COUNT];
 #define COUNT(c) (tl_counters[c]++)
+// Per-pixel condition flags (vpt_oracle_render_flags): which numerically ill-conditioned pieces of the reference a
+// pixel's paths went through.  Bit 0: sample_lights_pdf evaluated the pdf of an SDF light that the ray hit — the
+// reference takes that light's normal by finite differences at the SHADING point with h = flt_eps * distance
+// (yocto_pathtrace.cpp:389 -> yocto_sdfs.cpp:67-76), i.e. below the float spacing of the coordinates, so the normal
+// is rounding noise and one ulp in the direction changes the pdf by O(1) (tests/test_kat.py demonstrates it).
+enum { F_SDF_LIGHT_PDF = 1 };
+thread_local unsigned tl_flags;
 
 // ------------------------------------------------------------------------------------------------
 // rng (yocto_sampling.h:184-222)
@@ -1192,6 +1200,7 @@ float sample_lights_pdf(S& s, v3 position, v3 direction, int spheretrace_maxiter
       auto ray  = make_ray(position, direction);
       auto isec = spheretrace_one(s, ray, light.sdf, spheretrace_maxiter);
       if (isec.hit) {
+        tl_flags |= F_SDF_LIGHT_PDF;
         auto lposition = ray_point(ray, isec.dist);
         auto lnormal   = eval_sdf_normal_function(s.sdfs[isec.sdf], position, isec.dist);   // (sic) at `position`
         auto area      = cdf[light.cdf_len - 1];
@@ -1550,8 +1559,9 @@ shader_fn get_shader(int shader) {   // cpp:936-952
 // event counters (16 x u64, see enum above).  Threads pull pixel indices from an atomic counter
 // like yocto_parallel.h:189-212.
 // ------------------------------------------------------------------------------------------------
-extern "C" int vpt_oracle_render(const vpt_scene_desc* desc, const vpt_params* params, int nsamples, int width,
-    int height, float* image_rgba, int32_t* hits, uint64_t* rng, int* samples_io, int nthreads, uint64_t* counters) {
+static int oracle_render(const vpt_scene_desc* desc, const vpt_params* params, int nsamples, int width, int height,
+    float* image_rgba, int32_t* hits, uint64_t* rng, int* samples_io, int nthreads, uint64_t* counters, uint8_t* flags,
+    const int32_t* pixels, int npixels_listed) {
   if (!desc || !params || !image_rgba || !hits || !rng || !samples_io) return VPT_ERR_INVALID_ARG;
   auto shader = get_shader(params->shader);
   if (!shader) return VPT_ERR_UNKNOWN_SHADER;
@@ -1560,7 +1570,7 @@ extern "C" int vpt_oracle_render(const vpt_scene_desc* desc, const vpt_params* p
   auto  c      = ctx{*desc, *params};
   if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
   if (counters) std::memset(counters, 0, sizeof(uint64_t) * C_COUNT);
-  auto npixels = width * height;
+  auto npixels = pixels ? npixels_listed : width * height;
   for (auto pass = 0; pass < nsamples; pass++) {
     if (*samples_io >= params->samples) break;   // cpp:1055
     *samples_io += 1;
@@ -1570,9 +1580,11 @@ extern "C" int vpt_oracle_render(const vpt_scene_desc* desc, const vpt_params* p
     auto work    = [&](int tid) {
       std::memset(tl_counters, 0, sizeof(tl_counters));
       while (true) {
-        auto idx = next.fetch_add(1);
-        if (idx >= npixels) break;
+        auto k = next.fetch_add(1);
+        if (k >= npixels) break;
+        auto idx = pixels ? pixels[k] : k;
         auto i = idx % width, j = idx / width;
+        tl_flags = 0;
         auto r = rng_t{rng[2 * idx], rng[2 * idx + 1]};
         float u, v;
         if (preview) {
@@ -1592,6 +1604,7 @@ extern "C" int vpt_oracle_render(const vpt_scene_desc* desc, const vpt_params* p
         image_rgba[4 * idx + 2] += radiance.z, image_rgba[4 * idx + 3] += radiance.w;
         hits[idx] += 1;
         rng[2 * idx] = r.state, rng[2 * idx + 1] = r.inc;
+        if (flags) flags[idx] |= (uint8_t)tl_flags;
         COUNT(C_SAMPLES);
       }
       std::memcpy(&merged[C_COUNT * (size_t)tid], tl_counters, sizeof(tl_counters));
@@ -1608,6 +1621,26 @@ extern "C" int vpt_oracle_render(const vpt_scene_desc* desc, const vpt_params* p
         for (auto k = 0; k < C_COUNT; k++) counters[k] += merged[C_COUNT * (size_t)t + k];
   }
   return VPT_OK;
+}
+
+extern "C" int vpt_oracle_render(const vpt_scene_desc* desc, const vpt_params* params, int nsamples, int width,
+    int height, float* image_rgba, int32_t* hits, uint64_t* rng, int* samples_io, int nthreads, uint64_t* counters) {
+  return oracle_render(desc, params, nsamples, width, height, image_rgba, hits, rng, samples_io, nthreads, counters, nullptr, nullptr, 0);
+}
+// the same, also OR-ing each pixel's condition flags (F_* above) into flags[width * height]
+extern "C" int vpt_oracle_render_flags(const vpt_scene_desc* desc, const vpt_params* params, int nsamples, int width,
+    int height, float* image_rgba, int32_t* hits, uint64_t* rng, int* samples_io, int nthreads, uint8_t* flags) {
+  return oracle_render(desc, params, nsamples, width, height, image_rgba, hits, rng, samples_io, nthreads, nullptr, flags, nullptr, 0);
+}
+// the same for a subset of the frame: only the `npixels` row-major pixel indices listed in `pixels` are rendered
+// (each at most once); every other element of the state arrays is left untouched.  What one rank of a tile-sharded
+// render does; *samples_io advances as for the whole frame.
+extern "C" int vpt_oracle_render_pixels(const vpt_scene_desc* desc, const vpt_params* params, int nsamples, int width,
+    int height, float* image_rgba, int32_t* hits, uint64_t* rng, int* samples_io, int nthreads, const int32_t* pixels, int npixels) {
+  if (!pixels || npixels < 0) return VPT_ERR_INVALID_ARG;
+  for (auto k = 0; k < npixels; k++)
+    if (pixels[k] < 0 || pixels[k] >= width * height) return VPT_ERR_INVALID_ARG;
+  return oracle_render(desc, params, nsamples, width, height, image_rgba, hits, rng, samples_io, nthreads, nullptr, nullptr, pixels, npixels);
 }
 
 // intersect_bvh(bvh, scene, ray) / intersect_bvh(bvh, scene, instance, ray) (yocto_bvh.cpp:1097-1113) for a batch
@@ -1628,4 +1661,145 @@ extern "C" int vpt_oracle_intersect(const vpt_scene_desc* desc, int n, const flo
 extern "C" const char* vpt_oracle_counter_names() {
   return "samples,scene_nodes,shape_nodes,instance_tests,quad_tests,tri_tests,texel_f32,texel_u8,cdf_probes,"
          "surface_hits,volume_events,bounces,sdf_evals,voxel_fetches,light_pdf_hops";
+}
+
+// ------------------------------------------------------------------------------------------------
+// Known-answer-test twin of vpt_kat() (include/vpt_kat.h): the same ops and record layouts, evaluated by
+// the functions above.  tests/ compare it bit for bit with the tables the reference's own functions
+// produced (oracle/ref_tables.cpp -> tests/golden/kat_*.npz).
+// ------------------------------------------------------------------------------------------------
+namespace {
+const int kat_strides[VPT_KAT_OP_COUNT][2] = {{19, 22}, {15, 10}, {4, 4}, {5, 6}, {7, 5}, {7, 24}, {3, 3}, {7, 3}, {6, 1},
+    {6, 1}, {4, 3}, {6, 3}, {7, 4}, {4, 1}, {4, 1}};
+inline void put3(float* p, v3 v) { p[0] = v.x, p[1] = v.y, p[2] = v.z; }
+inline bool is_zero(v3 v) { return v == v3{0, 0, 0}; }
+}  // namespace
+
+extern "C" int vpt_oracle_kat(const vpt_scene_desc* desc, int op, int iparam, int n, const float* in, float* out) {
+  if (op < 0 || op >= VPT_KAT_OP_COUNT || n < 0 || (n > 0 && (!in || !out))) return VPT_ERR_INVALID_ARG;
+  auto scene_free = op == VPT_KAT_LOBES || op == VPT_KAT_MEDIA;
+  if (!desc && !scene_free) return VPT_ERR_INVALID_ARG;
+  auto si = kat_strides[op][0], so = kat_strides[op][1];
+  static const vpt_scene_desc empty = {};
+  S& s = desc ? *desc : empty;
+  for (auto r = 0; r < n; r++) {
+    auto a = in + (size_t)r * si;
+    auto o = out + (size_t)r * so;
+    for (auto k = 0; k < so; k++) o[k] = 0;
+    switch (op) {
+      case VPT_KAT_LOBES: {
+        auto m      = mpoint{};
+        m.type      = (int)a[0];
+        m.color     = to_v3(a + 1);
+        m.roughness = a[4], m.metallic = a[5], m.ior = a[6];
+        auto normal = to_v3(a + 7), outgoing = to_v3(a + 10);
+        auto rnl = a[13];
+        auto rn  = v2{a[14], a[15]};
+        auto alt = to_v3(a + 16);
+        auto s_in = sample_bsdfcos(m, normal, outgoing, rnl, rn);
+        put3(o, s_in);
+        if (!is_zero(s_in)) put3(o + 3, eval_bsdfcos(m, normal, outgoing, s_in)), o[6] = sample_bsdfcos_pdf(m, normal, outgoing, s_in);
+        put3(o + 7, eval_bsdfcos(m, normal, outgoing, alt));
+        o[10]     = sample_bsdfcos_pdf(m, normal, outgoing, alt);
+        auto d_in = sample_delta(m, normal, outgoing, rnl);
+        put3(o + 11, d_in);
+        if (!is_zero(d_in)) put3(o + 14, eval_delta(m, normal, outgoing, d_in)), o[17] = sample_delta_pdf(m, normal, outgoing, d_in);
+        put3(o + 18, eval_delta(m, normal, outgoing, alt));
+        o[21] = sample_delta_pdf(m, normal, outgoing, alt);
+      } break;
+      case VPT_KAT_MEDIA: {
+        auto density = to_v3(a);
+        auto maxd = a[3], rl = a[4], rd = a[5], g = a[6];
+        auto outgoing = to_v3(a + 7);
+        auto rn       = v2{a[10], a[11]};
+        auto incoming = to_v3(a + 12);
+        auto distance = sample_transmittance(density, maxd, rl, rd);
+        o[0] = distance, o[1] = sample_transmittance_pdf(density, distance, maxd);
+        put3(o + 2, eval_transmittance(density, distance));
+        o[5]       = eval_phasefunction(g, outgoing, incoming);
+        auto s_dir = sample_phasefunction(g, outgoing, rn);
+        put3(o + 6, s_dir);
+        o[9] = eval_phasefunction(g, outgoing, s_dir);
+      } break;
+      case VPT_KAT_TEXTURE: {
+        auto t = (int)a[0];
+        if (t < 0 || t >= s.num_textures) return VPT_ERR_INVALID_ARG;
+        auto c = eval_texture(s, s.textures[t], v2{a[1], a[2]}, a[3] != 0);
+        o[0] = c.x, o[1] = c.y, o[2] = c.z, o[3] = c.w;
+      } break;
+      case VPT_KAT_CAMERA: {
+        auto c = (int)a[0];
+        if (c < 0 || c >= s.num_cameras) return VPT_ERR_INVALID_ARG;
+        auto ray = eval_camera(s.cameras[c], v2{a[1], a[2]}, v2{a[3], a[4]});
+        put3(o, ray.o), put3(o + 3, ray.d);
+      } break;
+      case VPT_KAT_INTERSECT: {
+        auto ray  = make_ray(to_v3(a), to_v3(a + 3));
+        auto inst = (int)a[6];
+        if (inst >= s.num_instances) return VPT_ERR_INVALID_ARG;
+        auto isec = inst < 0 ? intersect_scene_bvh(s, ray) : intersect_instance_bvh(s, inst, ray);
+        o[0] = isec.hit ? (float)isec.instance : -1.0f, o[1] = isec.hit ? (float)isec.element : -1.0f;
+        o[2] = isec.hit ? isec.uv.x : 0, o[3] = isec.hit ? isec.uv.y : 0, o[4] = isec.hit ? isec.distance : 0;
+      } break;
+      case VPT_KAT_SURFACE: {
+        auto inst = (int)a[0], element = (int)a[1];
+        if (inst < 0 || inst >= s.num_instances) return VPT_ERR_INVALID_ARG;
+        auto& instance = s.instances[inst];
+        auto& sh       = s.shapes[instance.shape];
+        if (element < 0 || element >= (sh.num_triangles ? sh.num_triangles : sh.num_quads)) return VPT_ERR_INVALID_ARG;
+        auto uv = v2{a[2], a[3]};
+        auto outgoing = to_v3(a + 4);
+        put3(o, eval_position(s, instance, element, uv));   // eval_shading_position == eval_position for triangles / quads (yocto_scene.cpp:460-473)
+        put3(o + 3, eval_shading_normal(s, instance, element, uv, outgoing));
+        auto m = eval_material(s, instance, element, uv);
+        o[6]   = (float)m.type;
+        put3(o + 7, m.emission), put3(o + 10, m.color);
+        o[13] = m.opacity, o[14] = m.roughness, o[15] = m.metallic, o[16] = m.ior;
+        put3(o + 17, m.density), put3(o + 20, m.scattering);
+        o[23] = m.scanisotropy;
+      } break;
+      case VPT_KAT_ENVIRONMENT: put3(o, eval_environment(s, to_v3(a))); break;
+      case VPT_KAT_SAMPLE_LIGHTS:
+        if (s.num_lights <= 0) return VPT_ERR_INVALID_ARG;
+        put3(o, sample_lights(s, to_v3(a), a[3], a[4], v2{a[5], a[6]}));
+        break;
+      case VPT_KAT_LIGHTS_PDF:
+      case VPT_KAT_LIGHTS_PDF_K2:
+        if (s.num_lights <= 0) return VPT_ERR_INVALID_ARG;
+        o[0] = sample_lights_pdf(s, to_v3(a), to_v3(a + 3), iparam);
+        break;
+      case VPT_KAT_SDF_SCENE: {
+        auto res = eval_sdf_scene(s, to_v3(a), a[3]);
+        o[0] = res.result, o[1] = (float)res.instance, o[2] = (float)res.sdf;
+      } break;
+      case VPT_KAT_SDF_NORMAL: {
+        auto kind = (int)a[0], idx = (int)a[1];
+        if (kind == 0) {
+          if (idx < 0 || idx >= s.num_vol_instances) return VPT_ERR_INVALID_ARG;
+          put3(o, eval_sdf_normal_grid(s, s.vol_instances[idx], to_v3(a + 2), a[5]));
+        } else {
+          if (idx < 0 || idx >= s.num_sdfs) return VPT_ERR_INVALID_ARG;
+          put3(o, eval_sdf_normal_function(s.sdfs[idx], to_v3(a + 2), a[5]));
+        }
+      } break;
+      case VPT_KAT_SPHERETRACE: {
+        auto ray = make_ray(to_v3(a), to_v3(a + 3));
+        auto sdf = (int)a[6];
+        if (sdf >= s.num_sdfs) return VPT_ERR_INVALID_ARG;
+        auto res = sdf < 0 ? spheretrace(s, ray, iparam) : spheretrace_one(s, ray, sdf, iparam);
+        o[0] = res.hit ? 1.0f : 0.0f, o[1] = res.dist, o[2] = (float)res.instance, o[3] = (float)res.sdf;
+      } break;
+      case VPT_KAT_VOLUME: {
+        auto v = (int)a[0];
+        if (v < 0 || v >= s.num_volumes) return VPT_ERR_INVALID_ARG;
+        o[0] = eval_volume(s, s.volumes[v], to_v3(a + 1));
+      } break;
+      case VPT_KAT_SDF_FUNCTION: {
+        auto f = (int)a[0];
+        if (f < 0 || f >= s.num_sdfs) return VPT_ERR_INVALID_ARG;
+        o[0] = eval_sdf_function(s.sdfs[f], to_v3(a + 1));
+      } break;
+    }
+  }
+  return VPT_OK;
 }

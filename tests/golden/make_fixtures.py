@@ -19,30 +19,13 @@ import oracle_lib as O  # noqa: E402
 
 REF_SCENE = "/root/reference/tests/03_volume/volume.json"
 SCENES = os.path.join(HERE, "scenes")
+from cases import CASES as _CASES, EXTRA as _EXTRA  # noqa: E402
+
 # substitute scenes for the configs whose assets are missing (tests/golden/make_scenes.py); the reference's
 # own loader and renderer read them from here.  (name, scene, shader, resolution, samples, bounces, noimplicitmis)
-EXTRA = [
-    ("surf_path_96_4", "01_surface_min/surface_min.json", "pathtrace", 96, 4, 4, False),
-    ("surf_normal_96_1", "01_surface_min/surface_min.json", "normal", 96, 2, 4, False),
-    ("surf_eye_96_2", "01_surface_min/surface_min.json", "eyelight", 96, 2, 4, False),
-    ("head_vol_96_4", "05_head1ss_sub/head1ss_sub.json", "volpathtrace", 96, 4, 64, False),
-    ("sdf_implicit_96_4", "06_gridsdf_synth/gridsdf_synth.json", "implicit", 96, 4, 4, False),
-    ("sdf_nomis_96_4", "06_gridsdf_synth/gridsdf_synth.json", "implicit", 96, 4, 4, True),
-    ("sdf_normal_96_2", "06_gridsdf_synth/gridsdf_synth.json", "implicit_normal", 96, 2, 4, False),
-]
-
+EXTRA = [(name, *v) for name, v in _EXTRA.items()]
 # (name, shader, resolution, samples, bounces)
-CASES = [
-    ("vol_64_1", "volpathtrace", 64, 1, 64),      # samples==1: pixel-centre preview branch
-    ("vol_64_4", "volpathtrace", 64, 4, 64),
-    ("vol_96_16", "volpathtrace", 96, 16, 64),
-    ("path_64_4", "pathtrace", 64, 4, 4),
-    ("naive_64_4", "naive", 64, 4, 4),
-    ("eye_64_2", "eyelight", 64, 2, 4),
-    ("normal_64_2", "normal", 64, 2, 4),
-    ("texcoord_64_2", "texcoord", 64, 2, 4),
-    ("color_64_2", "color", 64, 2, 4),
-]
+CASES = [(name, *v) for name, v in _CASES.items()]
 
 
 def main():

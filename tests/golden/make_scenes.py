@@ -10,6 +10,14 @@ formulas (deterministic, no RNG).  Run from anywhere:  python tests/golden/make_
                    triangles, uniformly scaled frame) and the missing scattering texture dropped -> config 3
   06_gridsdf_synth tests/06_gridsdf/gridsdf.json with sdfs/sackboy.sdf / bunny.sdf generated here
                    (binary 48^3 sphere-union in mm, text 40^3 torus)              -> config 4
+  07_sdfunction_synth  tests/07_sdfunction/sdfunction.json (reflective x3, capped cone, torus, box light) with the
+                   same generated grids, plus sphere / bbox / plane SDFs and transparent (rough, delta, opacity < 1),
+                   delta reflective, refractive and gltfpbr materials: every sd_* primitive and every lobe the
+                   implicit shaders can reach                                      -> SURVEY 8(a) rows F18, S6
+  03_volume_lobes  tests/03_volume/volume.json with the five spheres' materials replaced by the lobes no reference
+                   scene with loadable assets uses on a mesh (delta + rough reflective, rough + delta transparent
+                   with opacity < 1, gltfpbr, subsurface) and an emissive sphere (a mesh light with a real BVH:
+                   the 100-hop pdf walk of yocto_pathtrace.cpp:363-378)            -> SURVEY 8(a) rows F17-F21
 """
 import json
 import os
@@ -89,8 +97,69 @@ def gridsdf_synth():
             f.write(" ".join(repr(float(v)) for v in flat[i:i + 8]) + "\n")
 
 
+def sdfunction_synth():
+    s = json.load(open(os.path.join(REF, "07_sdfunction", "sdfunction.json")))
+    s["textures"][0]["uri"] = "../03_volume/textures/sky.hdr"      # byte-identical to tests/07_sdfunction/textures/sky.hdr
+    s["volumes"] = [{"name": "sackboy", "uri": "../06_gridsdf_synth/sdfs/sackboy_synth.sdf", "binary": True},
+                    {"name": "bunny", "uri": "../06_gridsdf_synth/sdfs/bunny_synth.sdf", "binary": False}]
+    first = len(s["materials"])
+    s["materials"] += [
+        {"name": "frosted", "type": "transparent", "color": [0.9, 0.9, 1.0], "roughness": 0.2, "opacity": 0.7},
+        {"name": "mirror", "type": "reflective", "color": [0.9, 0.6, 0.3], "roughness": 0},
+        {"name": "thin", "type": "transparent", "color": [0.7, 1.0, 0.7], "roughness": 0},
+        {"name": "pbr", "type": "gltfpbr", "color": [0.8, 0.3, 0.3], "roughness": 0.3, "metallic": 0.7},
+        {"name": "ground", "type": "matte", "color": [0.3, 0.35, 0.4]},
+        {"name": "glass", "type": "refractive", "color": [1.0, 1.0, 1.0], "roughness": 0},
+    ]
+
+    def at(x, y, z):   # eval_sdf_scene applies the FORWARD frame to the world point (yocto_sdfs.cpp:13): local = p + o
+        return [1, 0, 0, 0, 1, 0, 0, 0, 1, -x, -y, -z]
+
+    s["sdfunctions"] += [
+        {"name": "sphere1", "type": "sphere", "radius": 0.05, "material": first + 0, "frame": at(-0.1, 0.05, 0.2)},
+        {"name": "sphere2", "type": "sphere", "radius": 0.04, "material": first + 1, "frame": at(0.0, 0.04, 0.35)},
+        {"name": "sphere3", "type": "sphere", "radius": 0.03, "material": first + 2, "frame": at(-0.2, 0.03, 0.05)},
+        {"name": "bbox1", "type": "bbox", "thickness": 0.008, "whd": [0.05, 0.05, 0.05], "material": first + 3,
+         "frame": at(-0.25, 0.06, 0.3)},
+        {"name": "plane1_far", "type": "plane", "material": first + 4, "frame": at(0, -0.3, 0)},
+        {"name": "sphere4", "type": "sphere", "radius": 0.03, "material": first + 5, "frame": at(-0.35, 0.03, -0.2)},
+    ]
+    os.makedirs(os.path.join(OUT, "07_sdfunction_synth"), exist_ok=True)
+    dump(os.path.join(OUT, "07_sdfunction_synth", "sdfunction_synth.json"), s)
+
+
+def volume_lobes():
+    s = json.load(open(os.path.join(REF, "03_volume", "volume.json")))
+    for shp in s["shapes"]:
+        shp["uri"] = "../03_volume/" + shp["uri"]
+    for t in s["textures"]:
+        t["uri"] = "../03_volume/" + t["uri"]
+    byname = {m["name"]: m for m in s["materials"]}
+    for name, new in {
+        "glass": {"type": "reflective", "color": [0.9, 0.7, 0.4], "roughness": 0},
+        "jade": {"type": "transparent", "color": [0.6, 0.9, 0.6], "roughness": 0.3},
+        "smoke": {"type": "gltfpbr", "color": [0.8, 0.3, 0.3], "roughness": 0.4, "metallic": 0.6},
+        "cloud": {"type": "transparent", "color": [0.8, 0.8, 1.0], "roughness": 0, "opacity": 0.6},
+        "skin": {"type": "subsurface", "color": [0.76, 0.48, 0.23], "roughness": 0.3, "scattering": [0.436, 0.227, 0.131],
+                 "scanisotropy": -0.8, "trdepth": 0.001},
+    }.items():
+        m = byname[name]
+        keep = m["name"]
+        m.clear()
+        m.update({"name": keep, **new})
+    s["materials"] += [{"name": "brushed", "type": "reflective", "color": [0.7, 0.7, 0.8], "roughness": 0.35},
+                       {"name": "glow", "type": "matte", "emission": [3, 2.5, 2], "color": [0, 0, 0]}]
+    n = len(s["materials"])
+    s["instances"] += [{"name": "brushed", "frame": [1, 0, 0, 0, 1, 0, 0, 0, 1, 0.6, 0, 0], "shape": 1, "material": n - 2},
+                       {"name": "glow", "frame": [1, 0, 0, 0, 1, 0, 0, 0, 1, -0.6, 0, 0.1], "shape": 1, "material": n - 1}]
+    os.makedirs(os.path.join(OUT, "03_volume_lobes"), exist_ok=True)
+    dump(os.path.join(OUT, "03_volume_lobes", "volume_lobes.json"), s)
+
+
 if __name__ == "__main__":
     surface_min()
     head1ss_sub()
     gridsdf_synth()
+    sdfunction_synth()
+    volume_lobes()
     print("scenes written under", OUT)

@@ -30,11 +30,33 @@ def lib():
     return _lib
 
 
-def oracle_render(host_scene, params, state, nsamples, nthreads=0, counters=False):
-    """Advance `state` by `nsamples` passes with the CPU oracle. Returns a counter dict if asked."""
+def oracle_render(host_scene, params, state, nsamples, nthreads=0, counters=False, flags=None, pixels=None):
+    """Advance `state` by `nsamples` passes with the CPU oracle. Returns a counter dict if asked.
+    flags: (h, w) uint8 array that receives each pixel's condition flags (bit 0: an SDF-light pdf was evaluated on a
+    hit; oracle/vpt_oracle.cpp).  pixels: int32 array of row-major pixel indices: render only those."""
     abi = params.to_abi()
     samples = C.c_int(state.samples)
     cnt = np.zeros(16, np.uint64)
+    common = (host_scene.desc, C.addressof(abi), nsamples, state.width, state.height, state.image.ctypes.data,
+              state.hits.ctypes.data, state.rngs.ctypes.data, C.byref(samples), nthreads)
+    if flags is not None or pixels is not None:
+        assert not counters and (flags is None or pixels is None)
+        if flags is not None:
+            assert flags.dtype == np.uint8 and flags.shape == (state.height, state.width) and flags.flags["C_CONTIGUOUS"]
+            fn = lib().vpt_oracle_render_flags
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                           C.POINTER(C.c_int), C.c_int, C.c_void_p]
+            rc = fn(*common, flags.ctypes.data)
+        else:
+            pixels = np.ascontiguousarray(pixels, np.int32)
+            fn = lib().vpt_oracle_render_pixels
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                           C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_int]
+            rc = fn(*common, pixels.ctypes.data, len(pixels))
+        if rc != 0:
+            raise RuntimeError(f"oracle failed: {rc}")
+        state.samples = samples.value
+        return None
     rc = lib().vpt_oracle_render(host_scene.desc, C.addressof(abi), nsamples, state.width, state.height,
                                  state.image.ctypes.data, state.hits.ctypes.data, state.rngs.ctypes.data,
                                  C.byref(samples), nthreads, cnt.ctypes.data if counters else None)

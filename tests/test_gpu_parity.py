@@ -15,6 +15,7 @@ import os
 import numpy as np
 import pytest
 
+from cases import EXTRA
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
@@ -198,25 +199,33 @@ def test_device_errors(vpt, scene03, dev03):
     assert rc == -1
 
 
-# ---- substitute scenes for BASELINE configs 1, 3, 4 (tests/golden/make_scenes.py) ---------------------------------
-EXTRA = {  # name -> (scene, shader, resolution, samples, bounces, noimplicit_mis, min fraction of identical streams)
-    "surf_path_96_4": ("01_surface_min/surface_min.json", "pathtrace", 96, 4, 4, False, 0.95),
-    "surf_normal_96_1": ("01_surface_min/surface_min.json", "normal", 96, 2, 4, False, 0.99),
-    "surf_eye_96_2": ("01_surface_min/surface_min.json", "eyelight", 96, 2, 4, False, 0.99),
-    "head_vol_96_4": ("05_head1ss_sub/head1ss_sub.json", "volpathtrace", 96, 4, 64, False, 0.90),
-    "sdf_implicit_96_4": ("06_gridsdf_synth/gridsdf_synth.json", "implicit", 96, 4, 4, False, 0.90),
-    "sdf_nomis_96_4": ("06_gridsdf_synth/gridsdf_synth.json", "implicit", 96, 4, 4, True, 0.90),
-    "sdf_normal_96_2": ("06_gridsdf_synth/gridsdf_synth.json", "implicit_normal", 96, 2, 4, False, 0.99),
+# ---- substitute scenes (tests/golden/make_scenes.py; cases: tests/cases.py) ----------------------------------------
+# Smallest share of pixels that must end with the reference's exact RNG state, set just under what MI355X measures
+# (printed by the test; DESIGN.md §2 lists the measured values).  Streams split where a last-bit libm difference
+# flips a discrete decision; the subsurface bunny (hundreds of scattering events per path) and the sphere-traced
+# SDFs (hundreds of dependent float steps per ray) amplify more than the quad scenes.
+MIN_SAME = {
+    "surf_path_96_4": 0.95, "surf_normal_96_1": 0.99, "surf_eye_96_2": 0.99, "head_vol_96_4": 0.90,
+    "sdf_implicit_96_4": 0.90, "sdf_nomis_96_4": 0.90, "sdf_normal_96_2": 0.99,
+    "sdfn_implicit_128_8": 0.90, "sdfn_nomis_128_4": 0.90, "sdfn_normal_128_2": 0.99,
+    "lobes_path_96_8": 0.90, "lobes_vol_96_8": 0.90, "lobes_naive_96_4": 0.90, "lobes_eye_96_2": 0.95,
 }
+assert set(MIN_SAME) == set(EXTRA)
 
 
 @pytest.mark.parametrize("name", sorted(EXTRA))
-def test_gpu_matches_reference_on_substitute_scenes(vpt, name):
-    """Against float32 states produced by the reference's own renderer on the substitute scenes.  The
-    subsurface bunny (hundreds of scattering events per path, each with logf/expf/sincos) and the
-    sphere-traced SDFs (up to 450 dependent float steps per ray) amplify last-bit libm differences, so
-    a larger share of pixel streams may diverge; the pixels that do replay must agree to 1e-3."""
-    scene_file, shader, res, spp, bounces, nomis, min_same = EXTRA[name]
+def test_gpu_matches_reference_on_substitute_scenes(vpt, oracle, name):
+    """Against float32 states produced by the reference's own renderer on the substitute scenes.
+
+    Pixels that consumed exactly the reference's random numbers (same RNG end state) must carry the reference's
+    radiance to 2e-3 — with ONE proven exclusion: pixels in which sample_lights_pdf evaluated the pdf of an SDF light
+    the ray hit.  The reference takes that light's normal by finite differences at the shading point with a step
+    below the float spacing of the coordinates (yocto_pathtrace.cpp:389), so the pdf is a discontinuous function of
+    the last bits of the position (tests/test_kat.py::test_sdf_light_pdf_is_ill_conditioned_in_the_reference: a
+    1-ulp nudge moves it by more than 2e-3 in 40 % of the cases) and the path weight with it, without changing the
+    number of draws.  The oracle (bit-identical to the reference) reports those pixels (flag bit 0); outside them
+    the check is strict, inside them only a quantile is required."""
+    scene_file, shader, res, spp, bounces, nomis = EXTRA[name]
     gold = np.load(os.path.join(GOLDEN, "substitute_states.npz"))
     scene = vpt.HostScene(os.path.join(GOLDEN, "scenes", scene_file))
     dev = vpt.DeviceScene(scene, 0)
@@ -226,14 +235,21 @@ def test_gpu_matches_reference_on_substitute_scenes(vpt, name):
     ref_img, ref_rng = gold[name + "_image"], gold[name + "_rngs"]
     assert (g.hits == spp).all()
     same = np.all(g.rngs == ref_rng, axis=-1)
-    print(name, "streams identical:", float(same.mean()))
-    assert same.mean() >= min_same, same.mean()
-    # identical streams, float radiance: a last-bit difference in a direction can still move an HDR
-    # environment lookup across a texel edge, so require 99 % of the replayed pixels within tolerance (e.g. an SDF-light pdf walk that grazes the
-    # light's edge flips between hit and miss without changing the number of draws)
-    close = np.all(np.isclose(g.image[same], ref_img[same], rtol=2e-3, atol=2e-3 * spp), axis=-1)
-    print(name, "replayed pixels within tolerance:", float(close.mean()), "worst abs diff", float(np.abs(g.image[same] - ref_img[same]).max()))
-    assert close.mean() >= 0.99
+    # the oracle's condition flags for the same render (and once more: it is the reference, bit for bit)
+    c = scene.make_state(p)
+    flags = np.zeros((c.height, c.width), np.uint8)
+    oracle.oracle_render(scene, p, c, spp, flags=flags)
+    assert np.array_equal(c.image.view(np.uint32), ref_img.view(np.uint32))
+    noisy = (flags & 1) != 0
+    close = np.all(np.isclose(g.image, ref_img, rtol=2e-3, atol=2e-3 * spp), axis=-1)
+    strict, loose = same & ~noisy, same & noisy
+    print(f"{name}: streams identical {same.mean():.4f}; well-conditioned replayed pixels {strict.sum()}, within tolerance "
+          f"{close[strict].mean() if strict.any() else 1.0:.5f} (worst abs diff {float(np.abs(g.image - ref_img)[strict].max()) if strict.any() else 0.0:.3g}); "
+          f"SDF-light-pdf pixels {loose.sum()}, within tolerance {close[loose].mean() if loose.any() else 1.0:.4f}")
+    assert same.mean() >= MIN_SAME[name], same.mean()
+    assert close[strict].all(), np.argwhere(strict & ~close)[:10].tolist()
+    if loose.any():
+        assert close[loose].mean() >= 0.80
     m_g, m_r = g.image[..., :3].mean(), ref_img[..., :3].mean()
     assert abs(m_g - m_r) <= 0.05 * abs(m_r) + 1e-6
 
@@ -314,32 +330,7 @@ def test_device_output_stage_matches_host_quantisation(vpt, scene03, dev03):
     assert (diff != 0).mean() < 1e-3
 
 
-def _edge_rays(rng, lo, hi, n):
-    """Rays path tracing rarely produces: axis-aligned and one-zero-component directions, origins on the
-    coordinate planes box faces tend to lie on (0*inf in the slab test), denormal direction components."""
-    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
-    d = rng.normal(size=(n, 3)).astype(np.float32)
-    d /= np.linalg.norm(d, axis=1, keepdims=True)
-    kind = np.arange(n) % 8
-    axis = rng.integers(0, 3, size=n)
-    sign = rng.choice(np.float32([-1, 1]), size=n)
-    for i in range(n):
-        k, a = kind[i], axis[i]
-        if k == 1:      # axis-aligned direction
-            d[i] = 0
-            d[i, a] = sign[i]
-        elif k == 2:    # one zero component
-            d[i, a] = 0
-        elif k == 3:    # zero component and the origin on that coordinate plane (grazes box faces at 0)
-            d[i, a] = 0
-            o[i, a] = 0
-        elif k == 4:    # denormal component: 1/d overflows
-            d[i, a] = np.float32(1e-40) * sign[i]
-        elif k == 5:    # tiny but normal component
-            d[i, a] = np.float32(1e-30) * sign[i]
-        elif k == 6:    # origin on a plane, direction not in it
-            o[i, a] = 0
-    return np.concatenate([o, d], axis=1)
+from kat_lib import edge_rays as _edge_rays  # noqa: E402
 
 
 @pytest.mark.parametrize("scene_file,lo,hi", [

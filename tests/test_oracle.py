@@ -9,12 +9,7 @@ import pytest
 
 from conftest import GOLDEN
 
-CASES = {  # name -> (shader, resolution, samples, bounces); see tests/golden/make_fixtures.py
-    "vol_64_1": ("volpathtrace", 64, 1, 64), "vol_64_4": ("volpathtrace", 64, 4, 64),
-    "vol_96_16": ("volpathtrace", 96, 16, 64), "path_64_4": ("pathtrace", 64, 4, 4),
-    "naive_64_4": ("naive", 64, 4, 4), "eye_64_2": ("eyelight", 64, 2, 4), "normal_64_2": ("normal", 64, 2, 4),
-    "texcoord_64_2": ("texcoord", 64, 2, 4), "color_64_2": ("color", 64, 2, 4),
-}
+from cases import CASES, EXTRA   # name -> parameters; see tests/cases.py and tests/golden/make_fixtures.py
 
 
 @pytest.fixture(scope="module")
@@ -92,18 +87,8 @@ def test_oracle_reproduces_instructor_image_lowres(vpt, scene03, oracle):
 
 
 # ---- substitute scenes (tests/golden/make_scenes.py): glossy + normal maps (config 1), 144k-triangle mesh with
-# ---- two environments and rough subsurface refraction (config 3), voxel-SDF + analytic SDFs + SDF light (config 4)
-EXTRA = {  # name -> (scene, shader, resolution, samples, bounces, noimplicit_mis)
-    "surf_path_96_4": ("01_surface_min/surface_min.json", "pathtrace", 96, 4, 4, False),
-    "surf_normal_96_1": ("01_surface_min/surface_min.json", "normal", 96, 2, 4, False),
-    "surf_eye_96_2": ("01_surface_min/surface_min.json", "eyelight", 96, 2, 4, False),
-    "head_vol_96_4": ("05_head1ss_sub/head1ss_sub.json", "volpathtrace", 96, 4, 64, False),
-    "sdf_implicit_96_4": ("06_gridsdf_synth/gridsdf_synth.json", "implicit", 96, 4, 4, False),
-    "sdf_nomis_96_4": ("06_gridsdf_synth/gridsdf_synth.json", "implicit", 96, 4, 4, True),
-    "sdf_normal_96_2": ("06_gridsdf_synth/gridsdf_synth.json", "implicit_normal", 96, 2, 4, False),
-}
-
-
+# ---- two environments and rough subsurface refraction (config 3), voxel-SDF + analytic SDFs + SDF light (config 4),
+# ---- every sd_* primitive and every BSDF lobe (07_sdfunction_synth, 03_volume_lobes): tests/cases.py EXTRA
 @pytest.fixture(scope="module")
 def substitute_states():
     return np.load(os.path.join(GOLDEN, "substitute_states.npz"))

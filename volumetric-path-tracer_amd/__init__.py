@@ -104,6 +104,10 @@ hip.vpt_intersect.argtypes = [_p, C.c_int, _p, C.c_int, _p, _p]
 hip.vpt_resolve_srgb8_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
 hip.vpt_selftest_reciprocal.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
 hip.vpt_selftest_light_cdf.argtypes = [_p, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
+hip.vpt_kat_strides.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+hip.vpt_kat.argtypes = [_p, C.c_int, C.c_int, C.c_int, _p, _p]
+hip.vpt_spheretrace.argtypes = [_p, C.c_int, _p, C.c_int, C.c_int, _p, _p]
+hip.vpt_eval_lobes.argtypes = [_p, C.c_int, _p, _p]
 host.vpth_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
 host.vpth_scene_load.restype = _p
 host.vpth_scene_free.argtypes = [_p]
@@ -205,6 +209,25 @@ class DeviceScene:
         ids, uvt = np.zeros((n, 2), np.int32), np.zeros((n, 3), np.float32)
         _check(hip.vpt_intersect(self.handle, n, rays.ctypes.data, instance, ids.ctypes.data, uvt.ctypes.data), "vpt_intersect")
         return ids, uvt
+
+    def kat(self, op: int, records: np.ndarray, iparam: int = 0) -> np.ndarray:
+        """vpt_kat (include/vpt_kat.h): run known-answer-test op `op` on an (n, in_stride) float32 array"""
+        si, so = C.c_int(), C.c_int()
+        _check(hip.vpt_kat_strides(op, C.byref(si), C.byref(so)), "vpt_kat_strides")
+        records = np.ascontiguousarray(records, np.float32)
+        if records.ndim != 2 or records.shape[1] != si.value:
+            raise VptError(f"KAT op {op} takes records of {si.value} floats")
+        out = np.zeros((records.shape[0], so.value), np.float32)
+        _check(hip.vpt_kat(self.handle, op, iparam, records.shape[0], records.ctypes.data, out.ctypes.data), "vpt_kat")
+        return out
+
+    def spheretrace(self, rays: np.ndarray, sdf: int = -1, maxiter: int = 450):
+        """vpt_spheretrace for an (n, 6) float32 array of rays {o, d}: (ids (n, 3) int32 {hit, instance, sdf}, t (n,) float32)"""
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = rays.shape[0]
+        ids, t = np.zeros((n, 3), np.int32), np.zeros((n,), np.float32)
+        _check(hip.vpt_spheretrace(self.handle, n, rays.ctypes.data, sdf, maxiter, ids.ctypes.data, t.ctypes.data), "vpt_spheretrace")
+        return ids, t
 
     def selftest_light_cdf(self, light: int, n: int = 1 << 20):
         """(mismatches, indexed) of the light-CDF search structure against the plain binary search (include/vpt.h)"""

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "vpt_stream_kernels.hip.h"
+#include "vpt_kat_kernels.hip.h"
 #include <rocprim/rocprim.hpp>
 
 // light_prims of the single-leaf mesh lights (vpt_device.h): one thread per (light, primitive of the leaf)
@@ -236,6 +237,10 @@ struct vpt_scene {
   bool       large_mesh_lights = false;
   long long  last_iterations = 0;
   int        trace_blocks = 1024;     // resident workgroups of the persistent trace kernel
+  // host mirrors of a few index tables: range checks of the batch entry points (vpt_intersect, vpt_kat)
+  std::vector<int> h_slot_of;                          // instance -> scene-BVH primitive slot (-1: not in the scene BVH)
+  std::vector<int> h_inst_shape, h_shape_elems, h_shape_elem_offset;
+  std::vector<int> h_prim_slot;                        // [shape elem_offset + element] -> slot in leaf_prims / leaf_attrs
 };
 
 namespace {
@@ -460,9 +465,12 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
         elems.push_back(make_int4(q[0], q[1], q[2], q[3]));
       }
     }
+    s->h_shape_elems.push_back(o.num_elems), s->h_shape_elem_offset.push_back(o.elem_offset);
+    s->h_prim_slot.resize(elems.size(), -1);
     // leaf records in BVH primitive order: slot k holds element prims[k]'s corners
     for (int k = 0; k < o.num_elems; k++) {
       int  e = d.shape_bvh_prims[sh.bvh_prim_offset + k];
+      s->h_prim_slot[(size_t)o.elem_offset + e] = o.leaf_offset + k;
       int4 q = elems[(size_t)o.elem_offset + e];
       for (int c = 0; c < 4; c++) {
         int    v = c == 0 ? q.x : c == 1 ? q.y : c == 2 ? q.z : q.w;
@@ -548,6 +556,8 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
     memcpy(&e[5], &tail[2], 16);
     slot_of[(size_t)id] = k;
   }
+  s->h_slot_of = slot_of;
+  for (int i = 0; i < d.num_instances; i++) s->h_inst_shape.push_back(d.instances[i].shape);
   std::vector<float4> env_inv((size_t)d.num_environments * 3), sdf_inv((size_t)d.num_sdfs * 3);
   for (int i = 0; i < d.num_environments; i++) pack_frame(hinverse(to_h(d.environments[i].frame), false), &env_inv[3 * (size_t)i]);
   for (int i = 0; i < d.num_sdfs; i++) pack_frame(hinverse(to_h(d.sdfs[i].frame), false), &sdf_inv[3 * (size_t)i]);
@@ -1044,7 +1054,8 @@ int vpt_selftest_reciprocal(int device, unsigned long long* mismatches, unsigned
 
 int vpt_intersect(vpt_scene* s, int n, const float* rays, int instance, int32_t* ids, float* uvt) {
   if (!s || !rays || !ids || !uvt || n < 0) return fail(VPT_ERR_INVALID_ARG, "bad argument");
-  if (instance >= s->d.num_instances) return fail(VPT_ERR_INVALID_ARG, "instance %d out of range", instance);
+  if (instance < -1 || instance >= s->d.num_instances) return fail(VPT_ERR_INVALID_ARG, "instance %d out of range", instance);
+  if (instance >= 0 && s->h_slot_of[(size_t)instance] < 0) return fail(VPT_ERR_INVALID_ARG, "instance %d is not in the scene BVH", instance);
   if (n == 0) return VPT_OK;
   HIP_TRY(hipSetDevice(s->device));
   float* d_rays = nullptr;
@@ -1066,6 +1077,89 @@ int vpt_intersect(vpt_scene* s, int n, const float* rays, int instance, int32_t*
   release();
   return ok ? VPT_OK : fail(VPT_ERR_HIP, "vpt_intersect failed to run");
 }
+
+// ---- known-answer-test entry points (include/vpt_kat.h) ------------------------------------------------------------
+static const int k_kat_strides[VPT_KAT_OP_COUNT][2] = {{19, 22}, {15, 10}, {4, 4}, {5, 6}, {7, 5}, {7, 24}, {3, 3}, {7, 3}, {6, 1},
+    {6, 1}, {4, 3}, {6, 3}, {7, 4}, {4, 1}, {4, 1}};
+
+int vpt_kat_strides(int op, int* in_stride, int* out_stride) {
+  if (op < 0 || op >= VPT_KAT_OP_COUNT || !in_stride || !out_stride) return fail(VPT_ERR_INVALID_ARG, "unknown KAT op %d", op);
+  *in_stride = k_kat_strides[op][0], *out_stride = k_kat_strides[op][1];
+  return VPT_OK;
+}
+
+int vpt_kat(vpt_scene* s, int op, int iparam, int n, const float* in, float* out) {
+  if (!s || n < 0 || (n > 0 && (!in || !out))) return fail(VPT_ERR_INVALID_ARG, "bad argument");
+  if (op < 0 || op >= VPT_KAT_OP_COUNT) return fail(VPT_ERR_INVALID_ARG, "unknown KAT op %d", op);
+  if (n == 0) return VPT_OK;
+  const int si = k_kat_strides[op][0], so = k_kat_strides[op][1];
+  const DScene& D = s->d;
+  // every id a record carries is checked here, so that no batch can index outside the scene's tables
+  std::vector<int> aux((size_t)n, 0);
+  auto id_ok = [](float v, int count) { return v >= 0 && v < (float)count && v == (float)(int)v; };
+  for (int i = 0; i < n; i++) {
+    const float* a = in + (size_t)i * si;
+    bool ok = true;
+    switch (op) {
+      case VPT_KAT_LOBES: ok = id_ok(a[0], VPT_MAT_GLTFPBR + 1); break;
+      case VPT_KAT_TEXTURE: ok = id_ok(a[0], D.num_textures); break;
+      case VPT_KAT_CAMERA: ok = id_ok(a[0], D.num_cameras); break;
+      case VPT_KAT_INTERSECT: ok = a[6] == -1.0f || (id_ok(a[6], D.num_instances) && s->h_slot_of[(size_t)a[6]] >= 0); break;
+      case VPT_KAT_SURFACE:
+        ok = id_ok(a[0], D.num_instances) && id_ok(a[1], s->h_shape_elems[(size_t)s->h_inst_shape[(size_t)a[0]]]);
+        if (ok) aux[(size_t)i] = s->h_prim_slot[(size_t)s->h_shape_elem_offset[(size_t)s->h_inst_shape[(size_t)a[0]]] + (size_t)a[1]];
+        break;
+      case VPT_KAT_SAMPLE_LIGHTS:
+      case VPT_KAT_LIGHTS_PDF:
+      case VPT_KAT_LIGHTS_PDF_K2: ok = D.num_lights > 0; break;
+      case VPT_KAT_SDF_NORMAL: ok = a[0] == 0.0f ? id_ok(a[1], D.num_vol_instances) : (a[0] == 1.0f && id_ok(a[1], D.num_sdfs)); break;
+      case VPT_KAT_SPHERETRACE: ok = a[6] == -1.0f || id_ok(a[6], D.num_sdfs); break;
+      case VPT_KAT_VOLUME: ok = id_ok(a[0], D.num_volumes); break;
+      case VPT_KAT_SDF_FUNCTION: ok = id_ok(a[0], D.num_sdfs); break;
+      default: break;
+    }
+    if (!ok) return fail(VPT_ERR_INVALID_ARG, "KAT op %d record %d: id out of range", op, i);
+  }
+  if ((op == VPT_KAT_LIGHTS_PDF || op == VPT_KAT_LIGHTS_PDF_K2 || op == VPT_KAT_SPHERETRACE) && (iparam < 0 || iparam > (1 << 20)))
+    return fail(VPT_ERR_INVALID_ARG, "KAT op %d: iteration limit %d out of range", op, iparam);
+  HIP_TRY(hipSetDevice(s->device));
+  float *d_in = nullptr, *d_out = nullptr;
+  int*   d_aux = nullptr;
+  auto   release = [&] { (void)hipFree(d_in), (void)hipFree(d_out), (void)hipFree(d_aux); };
+  if (hipMalloc((void**)&d_in, (size_t)n * si * 4) != hipSuccess || hipMalloc((void**)&d_out, (size_t)n * so * 4) != hipSuccess ||
+      hipMalloc((void**)&d_aux, (size_t)n * 4) != hipSuccess || hipMemcpy(d_in, in, (size_t)n * si * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_aux, aux.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    release();
+    return fail(VPT_ERR_HIP, "vpt_kat: device buffers");
+  }
+  int       blocks = (n + VPT_BLOCK - 1) / VPT_BLOCK;
+  stack_cfg stack;
+  if (int rc = stack_config(s, (long long)blocks * VPT_BLOCK, stack)) { release(); return rc; }
+  size_t lds4 = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int), lds2 = (size_t)s->stack_cap * VPT_BLOCK * sizeof(int);
+  size_t lds  = lds4 > lds2 ? lds4 : lds2;
+  if (stack.spill) hipLaunchKernelGGL(vpt_kat_kernel<true>, dim3(blocks), dim3(VPT_BLOCK), lds, 0, s->d, op, iparam, n, si, so, d_in, d_aux, d_out, stack, s->stack_cap);
+  else hipLaunchKernelGGL(vpt_kat_kernel<false>, dim3(blocks), dim3(VPT_BLOCK), lds, 0, s->d, op, iparam, n, si, so, d_in, d_aux, d_out, stack, s->stack_cap);
+  bool ok = hipGetLastError() == hipSuccess && hipMemcpy(out, d_out, (size_t)n * so * 4, hipMemcpyDeviceToHost) == hipSuccess;
+  release();
+  return ok ? VPT_OK : fail(VPT_ERR_HIP, "vpt_kat failed to run");
+}
+
+int vpt_spheretrace(vpt_scene* s, int n, const float* rays, int sdf, int maxiter, int32_t* ids, float* t) {
+  if (!s || n < 0 || (n > 0 && (!rays || !ids || !t))) return fail(VPT_ERR_INVALID_ARG, "bad argument");
+  std::vector<float> in((size_t)n * 7), out((size_t)n * 4);
+  for (int i = 0; i < n; i++) {
+    memcpy(&in[(size_t)i * 7], rays + (size_t)i * 6, 24);
+    in[(size_t)i * 7 + 6] = (float)(sdf < 0 ? -1 : sdf);
+  }
+  if (int rc = vpt_kat(s, VPT_KAT_SPHERETRACE, maxiter, n, in.data(), out.data())) return rc;
+  for (int i = 0; i < n; i++) {
+    ids[3 * (size_t)i] = (int)out[4 * (size_t)i], ids[3 * (size_t)i + 1] = (int)out[4 * (size_t)i + 2], ids[3 * (size_t)i + 2] = (int)out[4 * (size_t)i + 3];
+    t[i] = out[4 * (size_t)i + 1];
+  }
+  return VPT_OK;
+}
+
+int vpt_eval_lobes(vpt_scene* s, int n, const float* in19, float* out22) { return vpt_kat(s, VPT_KAT_LOBES, 0, n, in19, out22); }
 
 int vpt_selftest_light_cdf(vpt_scene* s, int light, int n, unsigned long long* mismatches, int* indexed) {
   if (!s || !mismatches || !indexed || n <= 0) return fail(VPT_ERR_INVALID_ARG, "bad argument");

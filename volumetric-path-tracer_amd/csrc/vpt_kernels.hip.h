@@ -1,16 +1,14 @@
-// vpt_kernels.hip.h — the render kernels.
+// vpt_kernels.hip.h — what the render kernels share (slot map, MIS direction choice, roulette, launch
+// schedule), K2 — the kernel of the two SDF shaders — and the elementwise state kernels.
 //
-// K1 vpt_render_kernel<SHADER>: one lane owns one pixel for the whole launch (all `nsamples`
-// passes), one wave64 owns one 8x8 pixel tile (64 consecutive slots of the tile-major state), a
-// 256-thread workgroup owns 4 tiles.  A lane keeps its pixel's PCG32 stream, radiance sum and hit
-// count in registers and touches HBM state exactly once per launch (coalesced 16 B/lane loads and
-// stores).  Paths are REGENERATED PER LANE: the reference's two nested loops (samples x bounces,
-// yocto_pathtrace.cpp:1081-1090 x 577-684) are flattened into one loop whose body is "one path
-// vertex", so a lane that finishes a short path starts its pixel's next sample immediately instead
-// of idling until the longest path of the wave ends.  Because a pixel's samples are still consumed
-// serially from its own stream, results are independent of how lanes interleave.
-//
-// Replaces: pathtrace_samples + shade_* (yocto_pathtrace.cpp:425-930, 1052-1092).
+// K2 vpt_render_kernel<K_IMPLICIT | K_IMPLICIT_NORMAL>: shade_implicit / shade_implicit_normal
+// (yocto_pathtrace.cpp:425-562) with the skeleton K1 uses (vpt_mesh_kernel.hip.h): one workgroup = one
+// wave64 = one 8x8 pixel tile of the tile-major state; one lane owns one pixel for the whole launch (all
+// `nsamples` passes) and keeps its PCG32 stream, radiance sum and hit count in registers, so HBM state is
+// read once and written once per launch; paths are regenerated per lane (the reference's samples x bounces
+// loops, cpp:1081-1090 x 441-532, flattened into one loop whose trip is one path vertex = one sphere trace +
+// shading), and a pixel's samples are consumed serially from its own stream, so results do not depend on how
+// lanes interleave.  Waves start longest first (sched_cfg).
 #pragma once
 #include "vpt_scene.hip.h"
 
@@ -31,15 +29,14 @@ VPT_DEV bool slot_to_pixel(const DParams& pr, int slot, int& px, int& py) {
   return px < pr.width && py < pr.height;
 }
 
-// MIS direction choice shared by the surface shaders (yocto_pathtrace.cpp:621-639, 728-746, 488-519).
+// MIS direction choice of shade_implicit (yocto_pathtrace.cpp:488-519; `noimplicit_mis` switches MIS off).
 // RNG draw order is the reference's right-to-left argument evaluation.
 // Returns false when the path ends (`incoming == 0`).
-template <bool MIS_ALWAYS>
 VPT_DEV bool next_direction(const DScene& sc, const DParams& pr, const mpoint& m, f3 normal, f3 outgoing, f3 position,
     rng_t& rng, f3& weight, f3& incoming, const lane_stack& stk) {
   incoming = mk3(0, 0, 0);
   if (!is_delta(m)) {
-    bool  mis  = MIS_ALWAYS || !pr.noimplicit_mis;
+    bool  mis  = !pr.noimplicit_mis;
     float coin = rand1f(rng);
     if (coin < (mis ? 0.5f : 1.0f)) {
       f2 rn;
@@ -111,7 +108,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
   ulonglong2 r_in   = rngs[slot];
   rng_t      rng    = {r_in.x, r_in.y};
   const vpt_camera& cam = sc.cameras[pr.camera];
-  const int nb = (SH == K_EYELIGHT) ? max(pr.bounces, 4) : pr.bounces;
+  const int nb = pr.bounces;
 
   // ---- path state --------------------------------------------------------------------------------
   ray_t ray    = make_ray(mk3(0, 0, 0), mk3(0, 0, 1));
@@ -119,10 +116,6 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
   float alpha  = 0;
   int   bounce = 0, sample = 0;
   bool  fresh  = true;
-  // 1-deep medium slot (the reference's vstack never holds more than one entry, cpp:644-647)
-  bool  in_medium = false;
-  f3    med_density = mk3(0, 0, 0), med_scattering = mk3(0, 0, 0), med_emission = mk3(0, 0, 0);
-  float med_g = 0;
 
   while (true) {
     if (fresh) {
@@ -140,23 +133,11 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
       ray    = eval_camera(cam, mk2(u, v), lens);
       radiance = mk3(0, 0, 0), weight = mk3(1, 1, 1);
       alpha = (SH == K_IMPLICIT) ? 1.0f : 0.0f;
-      bounce = 0, in_medium = false, fresh = false;
+      bounce = 0, fresh = false;
     }
 
     bool finish = false;
-    if constexpr (SH == K_DEBUG) {   // shade_normal / texcoord / color, cpp:893-930
-      hit_t h = trace_scene(sc, ray, stk);
-      if (h.hit) {
-        const DInstance& inst = sc.instances[h.instance];
-        if (pr.shader == VPT_SHADER_NORMAL) radiance = eval_shading_normal(sc, inst, h.element, h.uv, -ray.d);
-        else if (pr.shader == VPT_SHADER_TEXCOORD) {
-          f2 t = eval_texcoord(sc, inst, h.element, h.uv);
-          radiance = mk3(t.x, t.y, 0);
-        } else radiance = eval_material(sc, inst, h.element, h.uv).color;
-        alpha = 1;
-      }
-      finish = true;
-    } else if constexpr (SH == K_IMPLICIT_NORMAL) {   // cpp:538-562
+    if constexpr (SH == K_IMPLICIT_NORMAL) {   // cpp:538-562
       st_hit h = spheretrace(sc, ray, pr.spheretrace_maxiter);
       if (h.hit) {
         f3 position = ray_point(ray, h.dist);
@@ -168,7 +149,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
       finish = true;
     } else if (bounce >= nb) {
       finish = true;
-    } else if constexpr (SH == K_IMPLICIT) {   // shade_implicit, cpp:425-535
+    } else {   // shade_implicit, cpp:425-535
       st_hit h = spheretrace(sc, ray, pr.spheretrace_maxiter);
       if (!h.hit) {
         radiance = radiance + weight * eval_environment(sc, ray.d);
@@ -185,121 +166,12 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
         } else {
           radiance = radiance + weight * eval_emission(m.emission, normal, outgoing);
           f3 incoming;
-          if (!next_direction<false>(sc, pr, m, normal, outgoing, position, rng, weight, incoming, stk)) finish = true;
+          if (!next_direction(sc, pr, m, normal, outgoing, position, rng, weight, incoming, stk)) finish = true;
           else {
             ray = make_ray(position, incoming);
             if (!survive(weight, bounce, rng)) finish = true;
             bounce++;
           }
-        }
-      }
-    } else {   // surface shaders over the two-level BVH
-      hit_t h = trace_scene(sc, ray, stk);
-      if (!h.hit) {
-        radiance = radiance + weight * eval_environment(sc, ray.d);
-        finish   = true;
-      } else {
-        bool in_volume = false;
-        if constexpr (SH == K_VOLPATH) {
-          if (in_medium) {   // cpp:586-596 — rd is drawn before rl
-            float rd       = rand1f(rng);
-            float rl       = rand1f(rng);
-            float distance = sample_transmittance(med_density, h.distance, rl, rd);
-            weight = weight * (vexp3(-med_density * distance) / sample_transmittance_pdf(med_density, distance, h.distance));
-            in_volume  = distance < h.distance;
-            h.distance = distance;
-          }
-        }
-        if (!in_volume) {
-          const DInstance& inst = sc.instances[h.instance];
-          f3     outgoing = -ray.d;
-          f3     position = eval_position(sc, inst, h.element, h.uv);
-          f3     normal   = eval_shading_normal(sc, inst, h.element, h.uv, outgoing);
-          mpoint m        = eval_material(sc, inst, h.element, h.uv);
-          if (m.opacity < 1 && rand1f(rng) >= m.opacity) {
-            ray = make_ray(position + ray.d * 1e-2f, ray.d);   // bounce -= 1; continue
-          } else {
-            if (bounce == 0) alpha = 1;
-            radiance = radiance + weight * eval_emission(m.emission, normal, outgoing);
-            f3 incoming = mk3(0, 0, 0);
-            if constexpr (SH == K_EYELIGHT) {   // cpp:869-886
-              incoming = outgoing;
-              radiance = radiance + weight * VPT_PI * eval_bsdfcos(m, normal, outgoing, incoming);
-              if (!is_delta(m)) finish = true;
-              else {
-                incoming = sample_delta(m, normal, outgoing, rand1f(rng));
-                if (is_zero3(incoming)) finish = true;
-                else {
-                  weight = weight * (eval_delta(m, normal, outgoing, incoming) / sample_delta_pdf(m, normal, outgoing, incoming));
-                  if (is_zero3(weight) || !finite3(weight)) finish = true;
-                  else ray = make_ray(position, incoming);
-                }
-              }
-              bounce++;
-            } else if constexpr (SH == K_NAIVE) {   // cpp:802-828
-              if (m.roughness != 0) {
-                f2 rn;
-                rn.x      = rand1f(rng);
-                rn.y      = rand1f(rng);
-                float rnl = rand1f(rng);
-                incoming  = sample_bsdfcos(m, normal, outgoing, rnl, rn);
-                if (is_zero3(incoming)) finish = true;
-                else weight = weight * (eval_bsdfcos(m, normal, outgoing, incoming) / sample_bsdfcos_pdf(m, normal, outgoing, incoming));
-              } else {
-                incoming = sample_delta(m, normal, outgoing, rand1f(rng));
-                if (is_zero3(incoming)) finish = true;
-                else weight = weight * (eval_delta(m, normal, outgoing, incoming) / sample_delta_pdf(m, normal, outgoing, incoming));
-              }
-              if (!finish) {
-                if (!survive(weight, bounce, rng)) finish = true;
-                else ray = make_ray(position, incoming);
-              }
-              bounce++;
-            } else {   // pathtrace / volpathtrace
-              if (!next_direction<true>(sc, pr, m, normal, outgoing, position, rng, weight, incoming, stk)) finish = true;
-              else {
-                if constexpr (SH == K_VOLPATH) {   // cpp:641-648
-                  if (is_volumetric_type(sc.materials[inst.material].type) && dot(normal, outgoing) * dot(normal, incoming) < 0) {
-                    if (!in_medium) {
-                      in_medium   = true;
-                      med_density = m.density, med_scattering = m.scattering, med_emission = m.emission, med_g = m.scanisotropy;
-                    } else {
-                      in_medium = false;
-                    }
-                  }
-                }
-                ray = make_ray(position, incoming);
-                if (!survive(weight, bounce, rng)) finish = true;
-                bounce++;
-              }
-            }
-          }
-        } else {   // volume event, cpp:654-673
-          f3 outgoing = -ray.d;
-          f3 position = ray_point(ray, h.distance);
-          radiance = radiance + weight * eval_emission(med_emission, position, outgoing);   // (sic) cpp:660
-          f3 incoming;
-          if (rand1f(rng) < 0.5f) {
-            f2 rn;
-            rn.x = rand1f(rng);
-            rn.y = rand1f(rng);
-            (void)rand1f(rng);   // rnl is drawn and ignored, cpp:665
-            incoming = sample_phasefunction(med_g, outgoing, rn);
-          } else {
-            f2 ruv;
-            ruv.x     = rand1f(rng);
-            ruv.y     = rand1f(rng);
-            float rel = rand1f(rng);
-            float rl  = rand1f(rng);
-            incoming  = sample_lights(sc, position, rl, rel, ruv);
-          }
-          f3 f = med_density * med_scattering * eval_phasefunction(med_g, incoming, outgoing);
-          float pdf = 0.5f * eval_phasefunction(med_g, outgoing, incoming) +
-                      0.5f * sample_lights_pdf(sc, position, incoming, pr.spheretrace_maxiter, stk);
-          weight = weight * (f / pdf);
-          ray    = make_ray(position, incoming);
-          if (!survive(weight, bounce, rng)) finish = true;
-          bounce++;
         }
       }
     }

@@ -431,6 +431,39 @@ VPT_DEV float other_light_pdf(const DScene& sc, int light_id, int kind, float4 r
   return 0;
 }
 
+// one hop of the same walk for an emissive mesh with a real BVH (yocto_pathtrace.cpp:363-378): `h` is the hit of the
+// single-instance query from the walk's current position; returns the hop's pdf term and moves the walk on
+VPT_DEV float large_light_hop(const DScene& sc, int light_id, const hit_t& h, f3 position, f3 direction, f3& next_position) {
+  const vpt_light& light = sc.lights[light_id];
+  const DInstance& inst  = sc.instances[light.instance];
+  f3    lposition = eval_position(sc, inst, h.element, h.uv);
+  f3    lnormal   = eval_element_normal(sc, inst, h.element);
+  float area      = sc.light_cdf[light.cdf_offset + light.cdf_len - 1];
+  next_position   = lposition + direction * 1e-3f;
+  return distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * area);
+}
+
+// The shading point of a surface hit: eval_shading_position, eval_shading_normal and eval_material
+// (yocto_scene.cpp:460-579) in one go.  `prim` is the hit's slot in leaf_prims / leaf_attrs.
+VPT_DEV void eval_surface_point(const DScene& sc, const DInstance& inst, const vpt_material& mat, int prim, int element, f2 uv,
+    f3 outgoing, f3& position, f3& normal, mpoint& m) {
+  f2 texcoord;
+  f4 color_shp = mk4(1, 1, 1, 1);
+  if ((inst.shape_flags & (VPT_SHP_NORMALS | VPT_SHP_COLORS)) == VPT_SHP_NORMALS) {
+    // the common case: everything about the shading point sits behind the hit's primitive slot
+    eval_surface_slot(sc, inst, prim, uv, position, normal, texcoord);
+  } else {   // no vertex normals (element normal) or vertex colours: through the element's vertex indices
+    position  = eval_position(sc, inst, element, uv);
+    normal    = eval_normal(sc, inst, element, uv);
+    texcoord  = eval_texcoord(sc, inst, element, uv);
+    color_shp = eval_color(sc, inst, element, uv);
+  }
+  // eval_shading_normal, yocto_scene.cpp:476-503
+  if (mat.normal_tex != VPT_INVALID) normal = eval_normalmap(sc, inst, element, uv, normal, mat.normal_tex);
+  if (mat.type != VPT_MAT_REFRACTIVE && !(dot(normal, outgoing) >= 0)) normal = -normal;
+  m = eval_material_at(sc, mat, texcoord, color_shp);
+}
+
 enum { ST_NEW = 0, ST_MAIN = 1, ST_LPDF = 2 };
 
 #ifndef VPT_WAVES_PER_SIMD
@@ -518,13 +551,7 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
         // one hop of the mesh-light pdf loop, yocto_pathtrace.cpp:363-378 (position = ray.o, direction = ray.d)
         bool light_done = true;
         if (h.hit) {
-          const vpt_light& light = sc.lights[lp_light];
-          const DInstance& inst  = sc.instances[qinst];
-          f3    lposition = eval_position(sc, inst, h.element, h.uv);
-          f3    lnormal   = eval_element_normal(sc, inst, h.element);
-          float area      = sc.light_cdf[light.cdf_offset + light.cdf_len - 1];
-          lp_cur += distance_squared(lposition, ray.o) / (fabs_(dot(lnormal, ray.d)) * area);
-          lp_pos = lposition + ray.d * 1e-3f;
+          lp_cur += large_light_hop(sc, lp_light, h, ray.o, ray.d, lp_pos);
           lp_hop++;
           light_done = lp_hop >= 100;
         }
@@ -567,22 +594,7 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
         if (!in_volume) {
           const DInstance& inst = sc.instances[h.instance];
           VPT_T0(TM_SURF_GEOM);
-          const vpt_material& mat = sc.materials[inst.material];
-          f2 texcoord;
-          f4 color_shp = mk4(1, 1, 1, 1);
-          if ((inst.shape_flags & (VPT_SHP_NORMALS | VPT_SHP_COLORS)) == VPT_SHP_NORMALS) {
-            // the common case: everything about the shading point sits behind the hit's primitive slot
-            eval_surface_slot(sc, inst, h.prim, h.uv, position, normal, texcoord);
-          } else {   // no vertex normals (element normal) or vertex colours: through the element's vertex indices
-            position  = eval_position(sc, inst, h.element, h.uv);
-            normal    = eval_normal(sc, inst, h.element, h.uv);
-            texcoord  = eval_texcoord(sc, inst, h.element, h.uv);
-            color_shp = eval_color(sc, inst, h.element, h.uv);
-          }
-          // eval_shading_normal, yocto_scene.cpp:476-503
-          if (mat.normal_tex != VPT_INVALID) normal = eval_normalmap(sc, inst, h.element, h.uv, normal, mat.normal_tex);
-          if (mat.type != VPT_MAT_REFRACTIVE && !(dot(normal, outgoing) >= 0)) normal = -normal;
-          m = eval_material_at(sc, mat, texcoord, color_shp);
+          eval_surface_point(sc, inst, sc.materials[inst.material], h.prim, h.element, h.uv, outgoing, position, normal, m);
           VPT_T1(TM_SURF_GEOM);
           if (m.opacity < 1 && rand1f(rng) >= m.opacity) {
             ray = make_ray(position + ray.d * 1e-2f, ray.d);   // bounce -= 1; continue

@@ -1,4 +1,5 @@
-// vpt_scene.hip.h — device functions: two-level BVH traversal with LDS stacks, primitive tests,
+// vpt_scene.hip.h — device functions: primitive tests, the binary-node shape traversal behind K2's and the
+// stream pipeline's mesh-light pdf walk (K1 walks quad nodes: traverse(), vpt_mesh_kernel.hip.h),
 // scene/material/texture/environment evaluation, BSDF lobes, media, light sampling, SDF sphere
 // tracing.  Each function names the reference lines whose arithmetic it reproduces
 // (libs/yocto/*.h|cpp, libs/yocto_pathtrace/yocto_pathtrace.cpp).
@@ -139,40 +140,6 @@ VPT_DEV void to_instance_space(const DInstance& inst, f3 ro, f3 rd, f3& lo, f3& 
   lo = transform_point(inv, ro), ld = transform_vector(inv, rd);
 }
 
-// scene-level traversal, yocto_bvh.cpp:800-871
-VPT_DEV hit_t trace_scene(const DScene& sc, const ray_t& ray, const lane_stack& stk) {
-  hit_t r;
-  r.instance = -1, r.element = -1, r.uv = mk2(0, 0), r.distance = 0, r.hit = false;
-  if (sc.num_scene_nodes == 0) return r;
-  f3    ro = ray.o, rd = ray.d;
-  float tmin = ray.tmin, tmax = ray.tmax;
-  f3    dinv = mk3(1 / rd.x, 1 / rd.y, 1 / rd.z);
-  int   sgn  = (dinv.x < 0 ? 1 : 0) | (dinv.y < 0 ? 2 : 0) | (dinv.z < 0 ? 4 : 0);
-  int   sp   = 0;
-  stk.push(sp, 0);
-  while (sp != 0) {
-    int    n  = stk.pop(sp);
-    float4 n0 = sc.scene_nodes[2 * n], n1 = sc.scene_nodes[2 * n + 1];
-    if (!intersect_bbox(ro, dinv, tmin, tmax, mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y))) continue;
-    int start = __float_as_int(n1.z), meta = __float_as_int(n1.w);
-    if (meta >> 24) {
-      int axis = (meta >> 16) & 0xff;
-      if ((sgn >> axis) & 1) stk.push(sp, start), stk.push(sp, start + 1);
-      else stk.push(sp, start + 1), stk.push(sp, start);
-    } else {
-      int num = meta & 0xffff;
-      for (int k = 0; k < num; k++) {
-        int              id   = sc.scene_prims[start + k];
-        const DInstance& inst = sc.instances[id];
-        f3 lo, ld;
-        to_instance_space(inst, ro, rd, lo, ld);
-        if (trace_shape(sc, sc.shapes[inst.shape], lo, ld, tmin, tmax, stk, sp, r.element, r.uv, r.distance))
-          r.hit = true, r.instance = id, tmax = r.distance;
-      }
-    }
-  }
-  return r;
-}
 // single-instance query used by the light pdf, yocto_bvh.cpp:874-881
 VPT_DEV hit_t trace_instance(const DScene& sc, int instance, f3 o, f3 d, const lane_stack& stk) {
   hit_t r;

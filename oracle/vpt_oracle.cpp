@@ -96,8 +96,10 @@ inline v3 vmax3(v3 a, v3 b) { return {fmax_(a.x, b.x), fmax_(a.y, b.y), fmax_(a.
 inline v3 vclamp(v3 a, float lo, float hi) { return {clampf(a.x, lo, hi), clampf(a.y, lo, hi), clampf(a.z, lo, hi)}; }
 inline v3 vabs(v3 a) { return {fabs_(a.x), fabs_(a.y), fabs_(a.z)}; }
 inline v3 vsqrt(v3 a) { return {std::sqrt(a.x), std::sqrt(a.y), std::sqrt(a.z)}; }
-inline v3 vexp(v3 a) { return {std::exp(a.x), std::exp(a.y), std::exp(a.z)}; }
-inline v3 vlog(v3 a) { return {std::log(a.x), std::log(a.y), std::log(a.z)}; }
+inline float lm_exp(float x);
+inline float lm_log(float x);
+inline v3 vexp(v3 a) { return {lm_exp(a.x), lm_exp(a.y), lm_exp(a.z)}; }
+inline v3 vlog(v3 a) { return {lm_log(a.x), lm_log(a.y), lm_log(a.z)}; }
 inline float max3(v3 a) { return fmax_(fmax_(a.x, a.y), a.z); }    // :1691
 inline float min3(v3 a) { return fmin_(fmin_(a.x, a.y), a.z); }
 inline float sum3(v3 a) { return a.x + a.y + a.z; }
@@ -155,6 +157,32 @@ thread_local uint64_t tl_counters[C_COUNT];
 // is rounding noise and one ulp in the direction changes the pdf by O(1) (tests/test_kat.py demonstrates it).
 enum { F_SDF_LIGHT_PDF = 1 };
 thread_local unsigned tl_flags;
+
+// ------------------------------------------------------------------------------------------------
+// libm behind wrappers.  Normally they ARE the glibc float functions the reference calls (bit-identical results).
+// vpt_oracle_render_perturbed() switches on a per-pixel pseudo-random nudge of every result by -1 / 0 / +1 float ulp:
+// the only arithmetic in which the HIP path may differ from the reference is its libm (ocml, <= 1-2 ulp from glibc;
+// everything else is IEEE-exact and checked bit for bit by the known-answer tables), so "how much does the
+// REFERENCE'S OWN pixel move when its libm results move by an ulp" is the measured definition of a pixel on which
+// a faithful implementation may differ.  tests/test_gpu_parity.py is strict on every other pixel.
+// ------------------------------------------------------------------------------------------------
+enum { P_SINCOS = 1, P_ATAN = 2, P_EXPLOG = 4, P_POW = 8 };
+thread_local uint64_t tl_pert_state = 0;   // 0: off
+thread_local unsigned tl_pert_mask  = 0;
+inline float nudge(float r, unsigned cls) {
+  if (!tl_pert_state || !(tl_pert_mask & cls) || !std::isfinite(r)) return r;
+  tl_pert_state ^= tl_pert_state << 13, tl_pert_state ^= tl_pert_state >> 7, tl_pert_state ^= tl_pert_state << 17;   // xorshift64
+  auto pick = (tl_pert_state >> 32) % 3;
+  return pick == 0 ? r : std::nextafter(r, pick == 1 ? INFINITY : -INFINITY);
+}
+inline float lm_sin(float x) { return nudge(std::sin(x), P_SINCOS); }
+inline float lm_cos(float x) { return nudge(std::cos(x), P_SINCOS); }
+inline float lm_atan(float x) { return nudge(std::atan(x), P_ATAN); }
+inline float lm_atan2(float y, float x) { return nudge(std::atan2(y, x), P_ATAN); }
+inline float lm_acos(float x) { return nudge(std::acos(x), P_ATAN); }
+inline float lm_log(float x) { return nudge(std::log(x), P_EXPLOG); }
+inline float lm_exp(float x) { return nudge(std::exp(x), P_EXPLOG); }
+inline float lm_pow(float x, float y) { return nudge(std::pow(x, y), P_POW); }
 
 // ------------------------------------------------------------------------------------------------
 // rng (yocto_sampling.h:184-222)
@@ -544,7 +572,7 @@ v3 eval_environment(S& s, v3 direction) {
   for (auto e = 0; e < s.num_environments; e++) {
     auto& env = s.environments[e];
     auto  wl  = transform_direction(inverse(to_fr(env.frame), false), direction);
-    auto  texcoord = v2{std::atan2(wl.z, wl.x) / (2 * pif), std::acos(clampf(wl.y, -1.0f, 1.0f)) / pif};
+    auto  texcoord = v2{lm_atan2(wl.z, wl.x) / (2 * pif), lm_acos(clampf(wl.y, -1.0f, 1.0f)) / pif};
     if (texcoord.x < 0) texcoord.x += 1;
     emission += to_v3(env.emission) * xyz(eval_texture(s, env.emission_tex, texcoord, false));
   }
@@ -579,7 +607,7 @@ inline v3 sample_hemisphere_cos(v3 normal, v2 ruv) {
   auto z = std::sqrt(ruv.y);
   auto r = std::sqrt(1 - z * z);
   auto phi = 2 * pif * ruv.x;
-  auto local = v3{r * std::cos(phi), r * std::sin(phi), z};
+  auto local = v3{r * lm_cos(phi), r * lm_sin(phi), z};
   return transform_direction(basis_fromz(normal), local);
 }
 inline float sample_hemisphere_cos_pdf(v3 normal, v3 direction) {
@@ -590,7 +618,7 @@ inline v3 sample_sphere(v2 ruv) {
   auto z = 2 * ruv.y - 1;
   auto r = std::sqrt(clampf(1 - z * z, 0.0f, 1.0f));
   auto phi = 2 * pif * ruv.x;
-  return {r * std::cos(phi), r * std::sin(phi), z};
+  return {r * lm_cos(phi), r * lm_sin(phi), z};
 }
 inline v2 sample_triangle(v2 ruv) { return {1 - std::sqrt(ruv.x), ruv.y * std::sqrt(ruv.x)}; }
 inline int sample_uniform(int size, float r) { return clampi((int)(r * size), 0, size - 1); }
@@ -615,7 +643,7 @@ inline bool same_hemisphere(v3 n, v3 o, v3 i) { return dot(n, o) * dot(n, i) >= 
 inline v3 fresnel_schlick(v3 specular, v3 normal, v3 outgoing) {   // :302-308
   if (specular == v3{0, 0, 0}) return {0, 0, 0};
   auto cosine = dot(normal, outgoing);
-  return specular + (1 - specular) * std::pow(clampf(1 - fabs_(cosine), 0.0f, 1.0f), 5.0f);
+  return specular + (1 - specular) * lm_pow(clampf(1 - fabs_(cosine), 0.0f, 1.0f), 5.0f);
 }
 inline float fresnel_dielectric(float eta, v3 normal, v3 outgoing) {   // :311-331
   auto cosw = fabs_(dot(normal, outgoing));
@@ -673,8 +701,8 @@ inline float microfacet_shadowing(float roughness, v3 normal, v3 halfway, v3 out
 }
 inline v3 sample_microfacet(float roughness, v3 normal, v2 rn) {   // :450-463 (ggx)
   auto phi = 2 * pif * rn.x;
-  auto theta = std::atan(roughness * std::sqrt(rn.y / (1 - rn.y)));
-  auto local = v3{std::cos(phi) * std::sin(theta), std::sin(phi) * std::sin(theta), std::cos(theta)};
+  auto theta = lm_atan(roughness * std::sqrt(rn.y / (1 - rn.y)));
+  auto local = v3{lm_cos(phi) * lm_sin(theta), lm_sin(phi) * lm_sin(theta), lm_cos(theta)};
   return transform_direction(basis_fromz(normal), local);
 }
 inline float sample_microfacet_pdf(float roughness, v3 normal, v3 halfway) {   // :466-471
@@ -864,7 +892,7 @@ inline v3 eval_refractive(float ior, float roughness, v3 n, v3 o, v3 i) {
     auto D = microfacet_distribution(roughness, up, h);
     auto G = microfacet_shadowing(roughness, up, h, o, i);
     return v3{1, 1, 1} * fabs_((dot(o, h) * dot(i, h)) / (dot(o, n) * dot(i, n))) * (1 - F) * D * G /
-           std::pow(rel_ior * dot(h, i) + dot(h, o), 2.0f) * fabs_(dot(n, i));
+           lm_pow(rel_ior * dot(h, i) + dot(h, o), 2.0f) * fabs_(dot(n, i));
   }
 }
 inline v3 sample_refractive(float ior, float roughness, v3 n, v3 o, float rnl, v2 rn) {
@@ -891,7 +919,7 @@ inline float sample_refractive_pdf(float ior, float roughness, v3 n, v3 o, v3 i)
   } else {
     auto h = -normalize(rel_ior * i + o) * (entering ? 1.0f : -1.0f);
     return (1 - fresnel_dielectric(rel_ior, h, o)) * sample_microfacet_pdf(roughness, up, h) * fabs_(dot(h, i)) /
-           std::pow(rel_ior * dot(h, i) + dot(h, o), 2.0f);
+           lm_pow(rel_ior * dot(h, i) + dot(h, o), 2.0f);
   }
 }
 inline v3 eval_refractive_delta(float ior, v3 n, v3 o, v3 i) {
@@ -926,7 +954,7 @@ inline v3 eval_transmittance(v3 density, float distance) { return vexp(-density 
 inline float sample_transmittance(v3 density, float max_distance, float rl, float rd) {
   auto channel  = clampi((int)(rl * 3), 0, 2);
   auto dc       = comp(density, channel);
-  auto distance = (dc == 0) ? flt_max : -std::log(1 - rd) / dc;
+  auto distance = (dc == 0) ? flt_max : -lm_log(1 - rd) / dc;
   return fmin_(distance, max_distance);
 }
 inline float sample_transmittance_pdf(v3 density, float distance, float max_distance) {
@@ -948,7 +976,7 @@ inline v3 sample_phasefunction(float anisotropy, v3 outgoing, v2 rn) {
   }
   auto sin_theta = std::sqrt(fmax_(0.0f, 1 - cos_theta * cos_theta));
   auto phi = 2 * pif * rn.x;
-  auto local = v3{sin_theta * std::cos(phi), sin_theta * std::sin(phi), cos_theta};
+  auto local = v3{sin_theta * lm_cos(phi), sin_theta * lm_sin(phi), cos_theta};
   return mul(basis_fromz(-outgoing), local);
 }
 
@@ -1170,7 +1198,7 @@ v3 sample_lights(S& s, v3 position, float rl, float rel, v2 ruv) {
       auto  idx = sample_discrete(cdf, light.cdf_len, rel);
       auto  uv  = v2{((idx % tex.width) + 0.5f) / tex.width, ((idx / tex.width) + 0.5f) / tex.height};
       return transform_direction(to_fr(env.frame),
-          v3{std::cos(uv.x * 2 * pif) * std::sin(uv.y * pif), std::cos(uv.y * pif), std::sin(uv.x * 2 * pif) * std::sin(uv.y * pif)});
+          v3{lm_cos(uv.x * 2 * pif) * lm_sin(uv.y * pif), lm_cos(uv.y * pif), lm_sin(uv.x * 2 * pif) * lm_sin(uv.y * pif)});
     }
     return sample_sphere(ruv);
   }
@@ -1211,12 +1239,12 @@ float sample_lights_pdf(S& s, v3 position, v3 direction, int spheretrace_maxiter
       if (env.emission_tex != VPT_INVALID) {
         auto& tex = s.textures[env.emission_tex];
         auto  wl  = transform_direction(inverse(to_fr(env.frame), false), direction);
-        auto  texcoord = v2{std::atan2(wl.z, wl.x) / (2 * pif), std::acos(clampf(wl.y, -1.0f, 1.0f)) / pif};
+        auto  texcoord = v2{lm_atan2(wl.z, wl.x) / (2 * pif), lm_acos(clampf(wl.y, -1.0f, 1.0f)) / pif};
         if (texcoord.x < 0) texcoord.x += 1;
         auto i = clampi((int)(texcoord.x * tex.width), 0, tex.width - 1);
         auto j = clampi((int)(texcoord.y * tex.height), 0, tex.height - 1);
         auto prob  = sample_discrete_pdf(cdf, j * tex.width + i) / cdf[light.cdf_len - 1];
-        auto angle = (2 * pif / tex.width) * (pif / tex.height) * std::sin(pif * (j + 0.5f) / tex.height);
+        auto angle = (2 * pif / tex.width) * (pif / tex.height) * lm_sin(pif * (j + 0.5f) / tex.height);
         pdf += prob / angle;
       } else {
         pdf += 1 / (4 * pif);
@@ -1561,7 +1589,7 @@ shader_fn get_shader(int shader) {   // cpp:936-952
 // ------------------------------------------------------------------------------------------------
 static int oracle_render(const vpt_scene_desc* desc, const vpt_params* params, int nsamples, int width, int height,
     float* image_rgba, int32_t* hits, uint64_t* rng, int* samples_io, int nthreads, uint64_t* counters, uint8_t* flags,
-    const int32_t* pixels, int npixels_listed) {
+    const int32_t* pixels, int npixels_listed, uint64_t perturb_seed = 0, unsigned perturb_mask = 0) {
   if (!desc || !params || !image_rgba || !hits || !rng || !samples_io) return VPT_ERR_INVALID_ARG;
   auto shader = get_shader(params->shader);
   if (!shader) return VPT_ERR_UNKNOWN_SHADER;
@@ -1585,6 +1613,9 @@ static int oracle_render(const vpt_scene_desc* desc, const vpt_params* params, i
         auto idx = pixels ? pixels[k] : k;
         auto i = idx % width, j = idx / width;
         tl_flags = 0;
+        // libm perturbation (off unless asked): seeded by (seed, pixel, pass), so the result does not depend on the threads
+        tl_pert_mask  = perturb_mask;
+        tl_pert_state = perturb_seed ? (((perturb_seed * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)idx * 0xBF58476D1CE4E5B9ull) ^ ((uint64_t)(*samples_io) << 48)) | 1ull) : 0;
         auto r = rng_t{rng[2 * idx], rng[2 * idx + 1]};
         float u, v;
         if (preview) {
@@ -1605,6 +1636,7 @@ static int oracle_render(const vpt_scene_desc* desc, const vpt_params* params, i
         hits[idx] += 1;
         rng[2 * idx] = r.state, rng[2 * idx + 1] = r.inc;
         if (flags) flags[idx] |= (uint8_t)tl_flags;
+        tl_pert_state = 0;
         COUNT(C_SAMPLES);
       }
       std::memcpy(&merged[C_COUNT * (size_t)tid], tl_counters, sizeof(tl_counters));
@@ -1631,6 +1663,17 @@ extern "C" int vpt_oracle_render(const vpt_scene_desc* desc, const vpt_params* p
 extern "C" int vpt_oracle_render_flags(const vpt_scene_desc* desc, const vpt_params* params, int nsamples, int width,
     int height, float* image_rgba, int32_t* hits, uint64_t* rng, int* samples_io, int nthreads, uint8_t* flags) {
   return oracle_render(desc, params, nsamples, width, height, image_rgba, hits, rng, samples_io, nthreads, nullptr, flags, nullptr, 0);
+}
+// The same with every libm result of the shading path nudged by -1 / 0 / +1 float ulp, pseudo-randomly per pixel
+// (seed != 0; site_mask: 1 sin/cos, 2 atan/atan2/acos, 4 exp/log, 8 pow; 15 = all).  See the wrappers above.
+// `pixels` (optional): only those row-major pixel indices are rendered, as in vpt_oracle_render_pixels.
+extern "C" int vpt_oracle_render_perturbed(const vpt_scene_desc* desc, const vpt_params* params, int nsamples, int width,
+    int height, float* image_rgba, int32_t* hits, uint64_t* rng, int* samples_io, int nthreads, uint64_t seed, unsigned site_mask,
+    const int32_t* pixels, int npixels) {
+  if (seed == 0 || (pixels && npixels < 0)) return VPT_ERR_INVALID_ARG;
+  for (auto k = 0; pixels && k < npixels; k++)
+    if (pixels[k] < 0 || pixels[k] >= width * height) return VPT_ERR_INVALID_ARG;
+  return oracle_render(desc, params, nsamples, width, height, image_rgba, hits, rng, samples_io, nthreads, nullptr, nullptr, pixels, npixels, seed, site_mask);
 }
 // the same for a subset of the frame: only the `npixels` row-major pixel indices listed in `pixels` are rendered
 // (each at most once); every other element of the state arrays is left untouched.  What one rank of a tile-sharded

@@ -30,18 +30,28 @@ def lib():
     return _lib
 
 
-def oracle_render(host_scene, params, state, nsamples, nthreads=0, counters=False, flags=None, pixels=None):
+def oracle_render(host_scene, params, state, nsamples, nthreads=0, counters=False, flags=None, pixels=None, perturb=None):
     """Advance `state` by `nsamples` passes with the CPU oracle. Returns a counter dict if asked.
     flags: (h, w) uint8 array that receives each pixel's condition flags (bit 0: an SDF-light pdf was evaluated on a
-    hit; oracle/vpt_oracle.cpp).  pixels: int32 array of row-major pixel indices: render only those."""
+    hit; oracle/vpt_oracle.cpp).  pixels: int32 array of row-major pixel indices: render only those.
+    perturb: (seed, site_mask): nudge every libm result of the selected classes by -1 / 0 / +1 ulp (oracle/vpt_oracle.cpp);
+    may be combined with `pixels`."""
     abi = params.to_abi()
     samples = C.c_int(state.samples)
     cnt = np.zeros(16, np.uint64)
     common = (host_scene.desc, C.addressof(abi), nsamples, state.width, state.height, state.image.ctypes.data,
               state.hits.ctypes.data, state.rngs.ctypes.data, C.byref(samples), nthreads)
-    if flags is not None or pixels is not None:
-        assert not counters and (flags is None or pixels is None)
-        if flags is not None:
+    if flags is not None or pixels is not None or perturb is not None:
+        assert not counters and (flags is None or (pixels is None and perturb is None))
+        if perturb is not None:
+            fn = lib().vpt_oracle_render_perturbed
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                           C.POINTER(C.c_int), C.c_int, C.c_uint64, C.c_uint, C.c_void_p, C.c_int]
+            if pixels is not None:
+                pixels = np.ascontiguousarray(pixels, np.int32)
+            rc = fn(*common, int(perturb[0]), int(perturb[1]), pixels.ctypes.data if pixels is not None else None,
+                    len(pixels) if pixels is not None else 0)
+        elif flags is not None:
             assert flags.dtype == np.uint8 and flags.shape == (state.height, state.width) and flags.flags["C_CONTIGUOUS"]
             fn = lib().vpt_oracle_render_flags
             fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -64,6 +74,30 @@ def oracle_render(host_scene, params, state, nsamples, nthreads=0, counters=Fals
         raise RuntimeError(f"oracle failed: {rc}")
     state.samples = samples.value
     return dict(zip(COUNTER_NAMES, (int(x) for x in cnt))) if counters else None
+
+
+def unstable_pixels(host_scene, params, nsamples, ref_image, ref_rngs, make_state, rounds=16, rtol=1e-3, atol_per_sample=1e-3,
+                    pixels=None, first_seed=1):
+    """Pixels on which a faithful implementation may differ from the reference, MEASURED on the reference's own
+    arithmetic: re-render with every libm result nudged by -1 / 0 / +1 float ulp (`rounds` different pseudo-random
+    patterns, oracle/vpt_oracle.cpp) and mark the pixels whose RNG end state changes (a discrete decision flipped)
+    or whose radiance sum moves by more than rtol / atol (half of what the parity tests allow the device).
+    pixels: restrict the re-renders to these row-major indices (the others come back False).
+    Returns (stream_unstable, radiance_unstable) boolean (h, w) arrays."""
+    stream = np.zeros(ref_rngs.shape[:2], bool)
+    radiance = np.zeros(ref_rngs.shape[:2], bool)
+    chosen = np.ones(ref_rngs.shape[:2], bool)
+    if pixels is not None:
+        chosen[:] = False
+        chosen.reshape(-1)[np.asarray(pixels)] = True
+    for r in range(first_seed, first_seed + rounds):
+        q = make_state()
+        oracle_render(host_scene, params, q, nsamples, perturb=(r, 15), pixels=pixels)
+        same = np.all(q.rngs == ref_rngs, axis=-1)
+        close = np.all(np.isclose(q.image, ref_image, rtol=rtol, atol=atol_per_sample * nsamples), axis=-1)
+        stream |= chosen & ~same
+        radiance |= chosen & same & ~close
+    return stream, radiance
 
 
 def oracle_intersect(host_scene, rays, instance=-1):

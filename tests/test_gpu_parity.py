@@ -1,70 +1,90 @@
 """GPU parity tests (run on a real MI355X with -m gpu).  Everything goes through the C-ABI of
 libvpt_hip.so; the CPU oracle is only the checker.
 
-Tolerance model.  Integer work (PCG32 streams, hit counts) must be bit-exact.  Radiance is float32
-computed with the reference's operation order, but device libm (ocml sinf/cosf/logf/expf/powf/
-atan2f/acosf, <= 2 ulp) is not glibc's, so a small fraction of paths takes a different discrete
-decision somewhere (a Fresnel coin, a russian-roulette test, a silhouette hit) and that pixel's
-stream diverges from then on.  The tests therefore require (a) a large majority of pixels to end with
-the oracle's exact RNG state, (b) those pixels to agree to 1e-3 relative, and (c) whole-image
-statistics to agree within Monte-Carlo error.  Against the instructor images the bar is BASELINE's:
-per-channel RMS <= 2e-3 after the reference's sRGB8 + JPEG q75 stage."""
+Tolerance model.  Integer work (PCG32 streams, hit counts) must be bit-exact.  Radiance is float32 computed with
+the reference's operation order; every function on the path is checked against reference-made tables on identical
+inputs (tests/test_kat.py: bit-exact where no libm call is involved).  The one thing that is NOT the reference's is
+the device libm (ocml sinf / cosf / logf / expf / powf / atan2f / acosf / atanf, within 1-2 ulp of glibc's), and the
+reference amplifies a last-bit difference in two ways: it flips a discrete decision (a Fresnel coin, a roulette test,
+a silhouette hit, the texel an environment direction falls in) and the pixel's stream diverges from then on; or it
+lands in one of the reference's ill-conditioned finite differences — every SDF normal is taken with a step
+h = flt_eps * t, at or below the float spacing of the coordinates (yocto_sdfs.cpp:67-89), and sample_lights_pdf takes
+an SDF light's normal at the SHADING point (yocto_pathtrace.cpp:389) — and the radiance moves by percents while the
+pixel consumes exactly the same random numbers.
+
+Which pixels those are is MEASURED on the reference's own arithmetic instead of assumed: oracle_lib.unstable_pixels
+re-renders the case on the oracle (bit-identical to the reference) with every libm result nudged by -1 / 0 / +1 ulp
+and marks the pixels whose stream or radiance moves.  The checks are then
+ (a) STRICT: a pixel may differ from the reference (other RNG end state, or radiance off by more than 2e-3) only if
+     the reference's own value of that pixel moves (by more than 1e-3, or to another stream) under such nudges.
+     Two stages: 16 nudge patterns over the whole frame; the few disagreeing pixels those left unexplained (pixels
+     that move in a few per cent of the patterns only) get 2048 more patterns each.  A pixel that disagrees and is
+     stable under all of them fails the test;
+ (b) floors on the share of pixels with identical streams and on the share of stable pixels (so that the exclusion
+     cannot swallow the image), both set just under what MI355X measures (the tests print them);
+ (c) whole-image statistics within Monte-Carlo error.
+Against the instructor images the bar is BASELINE's: per-channel RMS <= 2e-3 after the reference's sRGB8 + JPEG q75
+stage."""
 import io
 import os
 
 import numpy as np
 import pytest
 
-from cases import EXTRA
+from cases import CASES, EXTRA
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-SHADERS = [("volpathtrace", 64, 4, 64), ("volpathtrace", 96, 16, 64), ("pathtrace", 64, 4, 4), ("naive", 64, 4, 4),
-           ("eyelight", 64, 2, 4), ("normal", 64, 2, 4), ("texcoord", 64, 2, 4), ("color", 64, 2, 4)]
+def _check_against_reference(oracle, scene, params, spp, g, ref_img, ref_rng, name, min_same, min_ok, min_stable):
+    """the strict check of the module docstring; g = device state, ref_* = the reference's state"""
+    assert g.samples == spp and (g.hits == spp).all()                 # integer: exact
+    same = np.all(g.rngs == ref_rng, axis=-1)                        # pixels that replayed the reference's paths
+    close = np.all(np.isclose(g.image, ref_img, rtol=2e-3, atol=2e-3 * spp), axis=-1)
+    fresh = lambda: scene.make_state(params)                         # noqa: E731
+    u_stream, u_rad = oracle.unstable_pixels(scene, params, spp, ref_img, ref_rng, fresh, rounds=16)
+    stable = ~(u_stream | u_rad)
+    ok = same & close
+    left = np.flatnonzero((stable & ~ok).reshape(-1))               # disagreeing pixels the 16 frame-wide patterns did not move
+    deep = 0
+    if 0 < len(left) <= 64:                                          # stage 2: 2048 more patterns on those pixels only
+        d_stream, d_rad = oracle.unstable_pixels(scene, params, spp, ref_img, ref_rng, fresh, rounds=2048, pixels=left, first_seed=1000)
+        deep = int((d_stream | d_rad).sum())
+        stable &= ~(d_stream | d_rad)
+    bad = stable & ~ok
+    rest = ~stable
+    print(f"{name}: streams identical {same.mean():.4f}; matching the reference {ok.mean():.4f}; stable under 1-ulp libm nudges {stable.mean():.4f} "
+          f"(stream-unstable {u_stream.mean():.4f}, radiance-unstable {u_rad.mean():.4f}, shown unstable only by the deep stage {deep}); "
+          f"unstable pixels matching {ok[rest].mean() if rest.any() else 1.0:.4f}; worst abs diff on stable pixels "
+          f"{float(np.abs(g.image - ref_img)[stable].max()):.3g}")
+    assert not bad.any(), (name, int(bad.sum()), np.argwhere(bad)[:10].tolist())
+    assert same.mean() >= min_same, (name, same.mean())
+    assert ok.mean() >= min_ok, (name, ok.mean())
+    assert stable.mean() >= min_stable, (name, stable.mean())
+    m_g, m_r = g.image[..., :3].mean(), ref_img[..., :3].mean()      # image-level agreement including the diverged pixels
+    assert abs(m_g - m_r) <= 0.03 * abs(m_r) + 1e-6
 
 
-def _pair(vpt, scene, dev, oracle, shader, res, spp, bounces, total=None):
-    p = vpt.PathtraceParams(resolution=res, samples=total or spp, shader=shader, bounces=bounces)
-    g = scene.make_state(p)
-    c = g.copy()
-    dev.pathtrace_samples(g, p, spp)
-    oracle.oracle_render(scene, p, c, spp)
-    return g, c
+# 03_volume, the reference's own assets (tests/cases.py CASES): floors just under the measured shares
+MIN_03 = {  # name -> floors on (identical streams, pixels matching the reference, stable pixels); measured: 1.0000, 1.0000 and
+    # 0.9716 / 0.9057 / 0.8479 for the three volumetric cases, 1.0000 otherwise (gpurun_out/r2c/tests.log, 2026-10-04)
+    "vol_64_1": (0.998, 0.998, 0.96), "vol_64_4": (0.998, 0.998, 0.89), "vol_96_16": (0.998, 0.998, 0.83),
+    "path_64_4": (0.998, 0.998, 0.998), "naive_64_4": (0.998, 0.998, 0.998), "eye_64_2": (0.998, 0.998, 0.998),
+    "normal_64_2": (0.998, 0.998, 0.998), "texcoord_64_2": (0.998, 0.998, 0.998), "color_64_2": (0.998, 0.998, 0.998),
+}
+assert set(MIN_03) == set(CASES)
 
 
-@pytest.mark.parametrize("shader,res,spp,bounces", SHADERS)
-def test_gpu_matches_oracle_small(vpt, scene03, dev03, oracle, shader, res, spp, bounces):
-    g, c = _pair(vpt, scene03, dev03, oracle, shader, res, spp, bounces)
-    assert g.samples == c.samples == spp
-    assert np.array_equal(g.hits, c.hits)                       # integer: exact
-    same = np.all(g.rngs == c.rngs, axis=-1)                    # pixels that replayed the oracle's paths
-    assert same.mean() >= 0.97, f"only {same.mean():.3f} of the pixel streams match the oracle"
-    a, b = g.image[same], c.image[same]
-    assert np.allclose(a, b, rtol=1e-3, atol=1e-4 * spp), float(np.abs(a - b).max())
-    # image-level agreement including the diverged pixels
-    assert abs(g.image[..., :3].mean() - c.image[..., :3].mean()) <= 0.02 * c.image[..., :3].mean() + 1e-6
-
-
-def test_gpu_matches_reference_fixtures(vpt, scene03, dev03):
-    """Same check directly against float32 states of the reference's own renderer."""
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_matches_reference_fixtures(vpt, scene03, dev03, oracle, name):
+    """float32 states of the reference's own renderer on tests/03_volume, every shader (samples == 1: the pixel-centre
+    preview branch, yocto_pathtrace.cpp:1059-1068)"""
+    shader, res, spp, bounces = CASES[name]
     gold = np.load(os.path.join(GOLDEN, "03_volume_states.npz"))
-    p = vpt.PathtraceParams(resolution=96, samples=16, shader="volpathtrace", bounces=64)
+    p = vpt.PathtraceParams(resolution=res, samples=spp, shader=shader, bounces=bounces)
     g = scene03.make_state(p)
-    dev03.pathtrace_samples(g, p, 16)
-    same = np.all(g.rngs == gold["vol_96_16_rngs"], axis=-1)
-    assert same.mean() >= 0.97
-    assert np.allclose(g.image[same], gold["vol_96_16_image"][same], rtol=1e-3, atol=2e-3)
-
-
-def test_preview_branch_samples_equal_one(vpt, scene03, dev03):
-    """params.samples == 1: pixel centres, no jitter draws (yocto_pathtrace.cpp:1059-1068)"""
-    gold = np.load(os.path.join(GOLDEN, "03_volume_states.npz"))
-    p = vpt.PathtraceParams(resolution=64, samples=1, shader="volpathtrace", bounces=64)
-    g = scene03.make_state(p)
-    dev03.pathtrace_samples(g, p, 1)
-    same = np.all(g.rngs == gold["vol_64_1_rngs"], axis=-1)
-    assert same.mean() >= 0.97 and np.allclose(g.image[same], gold["vol_64_1_image"][same], rtol=1e-3, atol=1e-4)
+    dev03.pathtrace_samples(g, p, spp)
+    _check_against_reference(oracle, scene03, p, spp, g, gold[name + "_image"], gold[name + "_rngs"], name, *MIN_03[name])
 
 
 def test_batching_and_sample_cap(vpt, scene03, dev03):
@@ -96,7 +116,7 @@ def test_resume_across_backends(vpt, scene03, dev03, oracle):
     oracle.oracle_render(scene03, p, mixed, 2)
     oracle.oracle_render(scene03, p, pure, 4)
     same = np.all(mixed.rngs == pure.rngs, axis=-1)
-    assert same.mean() >= 0.97 and np.allclose(mixed.image[same], pure.image[same], rtol=1e-3, atol=1e-3)
+    assert same.mean() >= 0.998 and np.allclose(mixed.image[same], pure.image[same], rtol=1e-3, atol=1e-3)   # measured 1.0000
 
 
 @pytest.mark.parametrize("nranks,tile", [(2, 8), (4, 16), (8, 8)])
@@ -137,21 +157,40 @@ def test_virtual_ranks_on_one_gpu_are_bit_identical(vpt, scene03, dev03, nranks,
     assert np.array_equal(frame.cpu().numpy().view(np.uint32), expect.view(np.uint32))
 
 
-def test_full_size_properties(vpt, scene03, dev03, oracle):
-    """BASELINE frame size 1280x533: size-independent properties + a low-res statistical cross-check."""
-    p = vpt.PathtraceParams(resolution=1280, samples=1 << 20, shader="volpathtrace", bounces=64)
-    g = scene03.make_state(p)
+FULL_SIZE = {  # BASELINE.json configs at their full frame sizes: (scene, shader, resolution, bounces, expected (w, h), spp)
+    "config2_03_volume_1280": ("03_volume/volume.json", "volpathtrace", 1280, 64, (1280, 533), 8),
+    "config3_05_head_1280": ("05_head1ss_sub/head1ss_sub.json", "volpathtrace", 1280, 64, (1280, 1280), 4),
+    "config4_06_gridsdf_1280": ("06_gridsdf_synth/gridsdf_synth.json", "implicit", 1280, 4, (1280, 533), 4),
+    "config5_03_volume_3840": ("03_volume/volume.json", "volpathtrace", 3840, 64, (3840, 1600), 2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FULL_SIZE))
+def test_full_size_properties(vpt, oracle, name):
+    """The BASELINE frame sizes: size-independent properties + a low-resolution statistical cross-check on the oracle."""
+    scene_file, shader, res, bounces, size, spp = FULL_SIZE[name]
+    scene = vpt.HostScene(os.path.join(GOLDEN, "scenes", scene_file))
+    dev = vpt.DeviceScene(scene, 0)
+    p = vpt.PathtraceParams(resolution=res, samples=1 << 20, shader=shader, bounces=bounces)
+    g = scene.make_state(p)
     before = g.rngs.copy()
-    dev03.pathtrace_samples(g, p, 8)
-    assert (g.width, g.height, g.samples) == (1280, 533, 8)
-    assert (g.hits == 8).all() and np.isfinite(g.image).all() and (g.image >= 0).all()
+    dev.pathtrace_samples(g, p, spp)
+    assert (g.width, g.height, g.samples) == (*size, spp)
+    assert (g.hits == spp).all() and np.isfinite(g.image).all() and (g.image >= 0).all()
     assert (g.rngs[..., 1] == before[..., 1]).all() and (g.rngs[..., 0] != before[..., 0]).all()  # inc fixed, state moved
-    assert (g.image[..., 3] <= 8).all()                       # alpha accumulates 0/1 per sample
-    # same scene at 320 wide on the oracle: mean radiance within MC error
-    q = vpt.PathtraceParams(resolution=320, samples=1 << 20, shader="volpathtrace", bounces=64)
-    c = scene03.make_state(q)
-    oracle.oracle_render(scene03, q, c, 8)
-    assert abs(g.image[..., :3].mean() / c.image[..., :3].mean() - 1) < 0.03
+    assert (g.image[..., 3] <= spp).all()                     # alpha accumulates 0/1 per sample
+    # batching is exact at full size too: the same frame in two launches ends in the same state, bit for bit
+    h = scene.make_state(p)
+    dev.pathtrace_samples(h, p, 1)
+    dev.pathtrace_samples(h, p, spp - 1)
+    assert np.array_equal(h.image.view(np.uint32), g.image.view(np.uint32)) and np.array_equal(h.rngs, g.rngs)
+    # same scene at 1/8 of the width on the oracle: mean radiance within MC error
+    q = vpt.PathtraceParams(resolution=res // 8, samples=1 << 20, shader=shader, bounces=bounces)
+    c = scene.make_state(q)
+    oracle.oracle_render(scene, q, c, 8)
+    ratio = (g.image[..., :3].mean() / spp) / (c.image[..., :3].mean() / 8)
+    print(name, "mean radiance device / oracle(low res):", ratio)
+    assert abs(ratio - 1) < 0.05
 
 
 def _rms_vs_check(vpt, state, check_name):
@@ -200,31 +239,28 @@ def test_device_errors(vpt, scene03, dev03):
 
 
 # ---- substitute scenes (tests/golden/make_scenes.py; cases: tests/cases.py) ----------------------------------------
-# Smallest share of pixels that must end with the reference's exact RNG state, set just under what MI355X measures
-# (printed by the test; DESIGN.md §2 lists the measured values).  Streams split where a last-bit libm difference
-# flips a discrete decision; the subsurface bunny (hundreds of scattering events per path) and the sphere-traced
-# SDFs (hundreds of dependent float steps per ray) amplify more than the quad scenes.
-MIN_SAME = {
-    "surf_path_96_4": 0.95, "surf_normal_96_1": 0.99, "surf_eye_96_2": 0.99, "head_vol_96_4": 0.90,
-    "sdf_implicit_96_4": 0.90, "sdf_nomis_96_4": 0.90, "sdf_normal_96_2": 0.99,
-    "sdfn_implicit_128_8": 0.90, "sdfn_nomis_128_4": 0.90, "sdfn_normal_128_2": 0.99,
-    "lobes_path_96_8": 0.90, "lobes_vol_96_8": 0.90, "lobes_naive_96_4": 0.90, "lobes_eye_96_2": 0.95,
+MIN_EXTRA = {  # name -> floors on (identical streams, pixels matching the reference, stable pixels), just under the measured
+    # shares (in the comments; gpurun_out/r2c/tests.log, 2026-10-04)
+    "surf_path_96_4": (0.997, 0.997, 0.985),        # 0.9995 0.9995 0.9927
+    "surf_normal_96_1": (0.998, 0.998, 0.998), "surf_eye_96_2": (0.998, 0.998, 0.998),   # 1.0000 1.0000 1.0000
+    "head_vol_96_4": (0.998, 0.998, 0.995),         # 1.0000 1.0000 0.9999
+    "sdf_implicit_96_4": (0.993, 0.985, 0.93),      # 0.9969 0.9909 0.9432
+    "sdf_nomis_96_4": (0.993, 0.987, 0.925),        # 0.9966 0.9922 0.9362
+    "sdf_normal_96_2": (0.998, 0.998, 0.998),       # 1.0000 1.0000 1.0000
+    "sdfn_implicit_128_8": (0.985, 0.97, 0.83),     # 0.9894 0.9761 0.8407
+    "sdfn_nomis_128_4": (0.984, 0.975, 0.865),      # 0.9885 0.9820 0.8782
+    "sdfn_normal_128_2": (0.998, 0.998, 0.998),     # 1.0000 1.0000 1.0000
+    "lobes_path_96_8": (0.998, 0.998, 0.995), "lobes_vol_96_8": (0.998, 0.998, 0.995),   # 1.0000 1.0000 0.9997 / 1.0000
+    "lobes_naive_96_4": (0.998, 0.998, 0.995), "lobes_eye_96_2": (0.998, 0.998, 0.998),  # 1.0000 1.0000 0.9997 / 1.0000
 }
-assert set(MIN_SAME) == set(EXTRA)
+assert set(MIN_EXTRA) == set(EXTRA)
 
 
 @pytest.mark.parametrize("name", sorted(EXTRA))
 def test_gpu_matches_reference_on_substitute_scenes(vpt, oracle, name):
-    """Against float32 states produced by the reference's own renderer on the substitute scenes.
-
-    Pixels that consumed exactly the reference's random numbers (same RNG end state) must carry the reference's
-    radiance to 2e-3 — with ONE proven exclusion: pixels in which sample_lights_pdf evaluated the pdf of an SDF light
-    the ray hit.  The reference takes that light's normal by finite differences at the shading point with a step
-    below the float spacing of the coordinates (yocto_pathtrace.cpp:389), so the pdf is a discontinuous function of
-    the last bits of the position (tests/test_kat.py::test_sdf_light_pdf_is_ill_conditioned_in_the_reference: a
-    1-ulp nudge moves it by more than 2e-3 in 40 % of the cases) and the path weight with it, without changing the
-    number of draws.  The oracle (bit-identical to the reference) reports those pixels (flag bit 0); outside them
-    the check is strict, inside them only a quantile is required."""
+    """float32 states of the reference's own renderer on the substitute scenes: glossy + normal maps, the 144k-triangle
+    subsurface bunny, voxel / analytic SDFs with an SDF light, every sd_* primitive and every BSDF lobe (rough and
+    delta), an emissive mesh with a real BVH."""
     scene_file, shader, res, spp, bounces, nomis = EXTRA[name]
     gold = np.load(os.path.join(GOLDEN, "substitute_states.npz"))
     scene = vpt.HostScene(os.path.join(GOLDEN, "scenes", scene_file))
@@ -232,26 +268,7 @@ def test_gpu_matches_reference_on_substitute_scenes(vpt, oracle, name):
     p = vpt.PathtraceParams(resolution=res, samples=spp, shader=shader, bounces=bounces, noimplicit_mis=nomis)
     g = scene.make_state(p)
     dev.pathtrace_samples(g, p, spp)
-    ref_img, ref_rng = gold[name + "_image"], gold[name + "_rngs"]
-    assert (g.hits == spp).all()
-    same = np.all(g.rngs == ref_rng, axis=-1)
-    # the oracle's condition flags for the same render (and once more: it is the reference, bit for bit)
-    c = scene.make_state(p)
-    flags = np.zeros((c.height, c.width), np.uint8)
-    oracle.oracle_render(scene, p, c, spp, flags=flags)
-    assert np.array_equal(c.image.view(np.uint32), ref_img.view(np.uint32))
-    noisy = (flags & 1) != 0
-    close = np.all(np.isclose(g.image, ref_img, rtol=2e-3, atol=2e-3 * spp), axis=-1)
-    strict, loose = same & ~noisy, same & noisy
-    print(f"{name}: streams identical {same.mean():.4f}; well-conditioned replayed pixels {strict.sum()}, within tolerance "
-          f"{close[strict].mean() if strict.any() else 1.0:.5f} (worst abs diff {float(np.abs(g.image - ref_img)[strict].max()) if strict.any() else 0.0:.3g}); "
-          f"SDF-light-pdf pixels {loose.sum()}, within tolerance {close[loose].mean() if loose.any() else 1.0:.4f}")
-    assert same.mean() >= MIN_SAME[name], same.mean()
-    assert close[strict].all(), np.argwhere(strict & ~close)[:10].tolist()
-    if loose.any():
-        assert close[loose].mean() >= 0.80
-    m_g, m_r = g.image[..., :3].mean(), ref_img[..., :3].mean()
-    assert abs(m_g - m_r) <= 0.05 * abs(m_r) + 1e-6
+    _check_against_reference(oracle, scene, p, spp, g, gold[name + "_image"], gold[name + "_rngs"], name, *MIN_EXTRA[name])
 
 
 def test_reciprocal_shortcut_is_exact_for_every_float(vpt):

@@ -58,10 +58,12 @@ def test_scene_bvh_lights_match_reference_hashes(scene03):
 
 
 def test_capi_exports_every_declared_symbol(vpt):
-    header = open(os.path.join(ROOT, "include", "vpt.h")).read()
-    names = set(re.findall(r"\b(vpt_[a-z_0-9]+)\s*\(", header))
+    names = set()
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):          # every header under include/: vpt.h, vpt_kat.h, ...
+        text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", h)).read(), flags=re.S)   # prototypes, not prose
+        names |= set(re.findall(r"\b(vpt_[a-z_0-9]+)\s*\(", text))
     names -= {"vpt_status"}
-    assert {"vpt_scene_create", "vpt_render", "vpt_render_device", "vpt_resolve_device"} <= names
+    assert {"vpt_scene_create", "vpt_render", "vpt_render_device", "vpt_resolve_device", "vpt_kat", "vpt_spheretrace"} <= names
     for name in sorted(names):
         assert hasattr(vpt.hip, name), f"libvpt_hip.so does not export {name}"
 

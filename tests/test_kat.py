@@ -104,12 +104,16 @@ def test_sdf_light_pdf_is_ill_conditioned_in_the_reference(oracle, host_scenes, 
 
 
 # ---- GPU: the kernels' own device functions against the same tables ------------------------------------------------
-# float32 ulps allowed per op where libm sits on the path; (ulps, minimum share of outputs within them).  The share is
-# below 1 only where a last-bit difference can move a discrete choice: the texel an environment-map direction falls in
-# (atan2 / acos -> integer texel), the Fresnel coin of a lobe sample (rnl < F), the lobe a sampled direction lands in.
-ULPS = {
-    "lobes": (64, 0.995), "media": (16, 1.0), "surface": (8, 1.0), "environment": (8, 0.995), "sample_lights": (8, 1.0),
-    "lights_pdf": (32, 0.995),
+# Per op with libm on its path: (float32 ulps, relative tolerance, minimum share of outputs within either).  The
+# relative tolerance covers outputs that are well-conditioned but not to the ulp: a bilinear environment lookup turns
+# one ulp of atan2 / acos (6e-8 of a texture coordinate) into 1.2e-4 of a texel at 2048 texels, i.e. up to ~1e-4 of the
+# interpolated radiance; the Henyey-Greenstein denominator 1 + g^2 - 2 g cos cancels to (1 - g)^2 in the forward
+# peak (g = 0.9: 150 ulp per ulp of the cosine).  The share is below 1 only where a last-bit difference moves a
+# DISCRETE choice and the output jumps: the Fresnel coin of a lobe sample (rnl < F) or the lobe a sampled direction
+# lands in (measured: 0.11 % of the lobe outputs).
+TOLERANCE = {
+    "lobes": (64, 1e-5, 0.995), "media": (16, 2e-5, 1.0), "surface": (8, 0.0, 1.0), "environment": (8, 5e-4, 1.0),
+    "sample_lights": (8, 5e-5, 1.0), "lights_pdf": (32, 0.0, 1.0),
 }
 
 
@@ -126,13 +130,15 @@ def test_device_reproduces_reference_tables(vpt, host_scenes, tables, case):
             ok = K.bits_equal(got, ref)
             assert ok.all(), (case, o, int((~ok).sum()), np.argwhere(~ok)[:5].tolist())
             continue
-        ulps, share = ULPS[op]
+        ulps, rel, share = TOLERANCE[op]
         d = K.ulp_distance(got, ref)
-        # absolute floor for values that are sums / differences near zero (a cancelling dot product has no ulp meaning)
-        close = (d <= ulps) | (np.abs(got - ref) <= 1e-6 * np.maximum(1.0, np.abs(ref)))
+        with np.errstate(invalid="ignore"):
+            err = np.abs(got - ref)
+            # absolute floor 1e-6 for values that are sums / differences near zero (a cancelling dot product has no ulp meaning)
+            close = (d <= ulps) | (err <= np.maximum(rel * np.abs(ref), 1e-6 * np.maximum(1.0, np.abs(ref))))
         frac = close.mean()
         worst = d[~close].max() if (~close).any() else d.max()
-        print(f"{case}/{o}: within {ulps} ulp: {frac:.5f}; exact: {(d == 0).mean():.4f}; worst {worst}")
+        print(f"{case}/{o}: within {ulps} ulp or {rel:g} relative: {frac:.5f}; exact: {(d == 0).mean():.4f}; worst ulp distance {worst}")
         assert frac >= share, (case, o, frac, np.argwhere(~close)[:5].tolist())
 
 

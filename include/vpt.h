@@ -280,7 +280,9 @@ int vpt_resolve_device(const vpt_layout* layout, const void* d_tiles_all_ranks, 
 int vpt_resolve_srgb8_device(const vpt_layout* layout, const void* d_tiles_all_ranks, int samples,
                              void* d_rgba8_rowmajor, void* stream);
 
-/* per-launch profile of the last vpt_render_device on this scene (HIP events on `stream`) */
+/* per-launch profile of the last vpt_render_device on this scene (HIP events on `stream`); synchronises with that
+ * launch.  Like vpt_render it returns VPT_ERR_HIP if a wave of the implicit kernel gave up on its watchdog (a wave
+ * that has not finished after 300 s leaves the kernel instead of holding the GPU: a defect, never a workload). */
 int vpt_last_kernel_ms(vpt_scene* scene, float* ms);
 
 /* intersect_bvh(bvh, scene, ray) (instance < 0) / intersect_bvh(bvh, scene, instance, ray) of yocto_bvh.h, for a

@@ -147,7 +147,9 @@ inline v3 to_v3(const float* p) { return {p[0], p[1], p[2]}; }
 // ------------------------------------------------------------------------------------------------
 enum { C_SAMPLES, C_SCENE_NODES, C_SHAPE_NODES, C_INSTANCE_TESTS, C_QUAD_TESTS, C_TRI_TESTS,
   C_TEXEL_F32, C_TEXEL_U8, C_CDF_PROBES, C_SURFACE_HITS, C_VOLUME_EVENTS, C_BOUNCES, C_SDF_EVALS,
-  C_VOXEL_FETCHES, C_LIGHT_PDF_HOPS, C_COUNT = 16 };
+  C_VOXEL_FETCHES, C_LIGHT_PDF_HOPS,
+  // sphere-trace profile: marches, their steps by outcome (hit / ran out of iterations / t overflowed), steps taken beyond t = 16
+  C_MARCHES, C_STEPS_HIT, C_STEPS_MAXITER, C_STEPS_ESCAPED, C_STEPS_FAR, C_LIGHT_MARCH_STEPS, C_COUNT = 24 };
 thread_local uint64_t tl_counters[C_COUNT];
 #define COUNT(c) (tl_counters[c]++)
 // Per-pixel condition flags (vpt_oracle_render_flags): which numerically ill-conditioned pieces of the reference a
@@ -1157,6 +1159,7 @@ st_result spheretrace_one(S& s, const ray3& ray, int sdf_handle, int maxiter) { 
   for (int i = 0; i < maxiter && t < ray.tmax; ++i) {
     auto p   = ray_point(ray, t);
     auto res = eval_sdf_function(sdf, transform_point(to_fr(sdf.frame), p));
+    tl_counters[C_LIGHT_MARCH_STEPS]++;
     if (fabs_(res) < (flt_eps * t)) return {true, t, -1, sdf_handle};
     t += res;
   }
@@ -1164,12 +1167,19 @@ st_result spheretrace_one(S& s, const ray3& ray, int sdf_handle, int maxiter) { 
 }
 st_result spheretrace(S& s, const ray3& ray, int maxiter) {   // yocto_pathtrace.cpp:289-307
   auto t = ray.tmin;
-  for (int i = 0; i < maxiter && t < ray.tmax; ++i) {
+  auto i = 0;
+  tl_counters[C_MARCHES]++;
+  for (; i < maxiter && t < ray.tmax; ++i) {
     auto p   = ray_point(ray, t);
     auto res = eval_sdf_scene(s, p, t);
-    if (fabs_(res.result) < (flt_eps * t)) return {true, t, res.instance, res.sdf};
+    if (t > 16) tl_counters[C_STEPS_FAR]++;
+    if (fabs_(res.result) < (flt_eps * t)) {
+      tl_counters[C_STEPS_HIT] += i + 1;
+      return {true, t, res.instance, res.sdf};
+    }
     t += res.result;
   }
+  tl_counters[i >= maxiter ? C_STEPS_MAXITER : C_STEPS_ESCAPED] += i;
   return {};
 }
 
@@ -1584,7 +1594,7 @@ shader_fn get_shader(int shader) {   // cpp:936-952
 
 // ------------------------------------------------------------------------------------------------
 // entry point: same contract as vpt_render() in include/vpt.h, plus a thread count and optional
-// event counters (16 x u64, see enum above).  Threads pull pixel indices from an atomic counter
+// event counters (24 x u64, see enum above).  Threads pull pixel indices from an atomic counter
 // like yocto_parallel.h:189-212.
 // ------------------------------------------------------------------------------------------------
 static int oracle_render(const vpt_scene_desc* desc, const vpt_params* params, int nsamples, int width, int height,
@@ -1703,7 +1713,8 @@ extern "C" int vpt_oracle_intersect(const vpt_scene_desc* desc, int n, const flo
 
 extern "C" const char* vpt_oracle_counter_names() {
   return "samples,scene_nodes,shape_nodes,instance_tests,quad_tests,tri_tests,texel_f32,texel_u8,cdf_probes,"
-         "surface_hits,volume_events,bounces,sdf_evals,voxel_fetches,light_pdf_hops";
+         "surface_hits,volume_events,bounces,sdf_evals,voxel_fetches,light_pdf_hops,marches,steps_hit,steps_maxiter,"
+         "steps_escaped,steps_far,light_march_steps";
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,10 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 
 
 def counters(directory, kernel):
-    """per counter: value of the LAST dispatch of `kernel` (the timed launch), summed over its rows (XCDs / dimensions)"""
+    """per counter: value of the LAST dispatch of `kernel` (the timed launch), summed over its rows (XCDs / dimensions).
+    Reads rocprofv3's CSV output or, where it wrote its default rocpd database, the counters_collection view of that."""
     rows = []
     for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
         rows += [r for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"]]
+    for f in glob.glob(os.path.join(directory, "**", "*_results.db"), recursive=True):
+        import sqlite3
+        cur = sqlite3.connect(f).execute("select dispatch_id, counter_name, value from counters_collection where kernel_name like ?", (f"%{kernel}%",))
+        rows += [{"Dispatch_Id": d, "Counter_Name": n, "Counter_Value": v} for d, n, v in cur]
     if not rows:
         return {}
     last = max(int(r["Dispatch_Id"]) for r in rows)
@@ -39,6 +44,17 @@ def main():
         keep = [r for r in csv.reader(open(f))]
         with open(dst + "_kernel_stats.csv", "w", newline="") as out:
             csv.writer(out).writerows(keep)
+    for f in glob.glob(os.path.join(src, "stats", "**", "*_results.db"), recursive=True):   # rocpd database: the same summary
+        import sqlite3
+        con = sqlite3.connect(f)
+        rows = con.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by 3 desc").fetchall()
+        total = sum(r[2] for r in rows) or 1
+        with open(dst + "_kernel_stats.csv", "w", newline="") as out:
+            w = csv.writer(out)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for name, calls, tot, avg, mn, mx in rows:
+                short = name if len(name) < 160 else name[:157] + "..."
+                w.writerow([short, calls, int(tot), round(avg, 1), round(100.0 * tot / total, 4), int(mn), int(mx)])
     fetch, write = counters(os.path.join(src, "fetch"), kernel), counters(os.path.join(src, "write"), kernel)
     if fetch or write:
         samples = line["config"]["samples_per_step"] if line else None

@@ -14,7 +14,8 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "libvpt_oracle.so")
 REF_DRIVER = os.path.join(ORACLE_DIR, "_ref", "ref_driver")
 COUNTER_NAMES = ("samples,scene_nodes,shape_nodes,instance_tests,quad_tests,tri_tests,texel_f32,texel_u8,"
-                 "cdf_probes,surface_hits,volume_events,bounces,sdf_evals,voxel_fetches,light_pdf_hops").split(",")
+                 "cdf_probes,surface_hits,volume_events,bounces,sdf_evals,voxel_fetches,light_pdf_hops,marches,steps_hit,"
+                 "steps_maxiter,steps_escaped,steps_far,light_march_steps").split(",")
 
 _lib = None
 
@@ -38,7 +39,7 @@ def oracle_render(host_scene, params, state, nsamples, nthreads=0, counters=Fals
     may be combined with `pixels`."""
     abi = params.to_abi()
     samples = C.c_int(state.samples)
-    cnt = np.zeros(16, np.uint64)
+    cnt = np.zeros(24, np.uint64)
     common = (host_scene.desc, C.addressof(abi), nsamples, state.width, state.height, state.image.ctypes.data,
               state.hits.ctypes.data, state.rngs.ctypes.data, C.byref(samples), nthreads)
     if flags is not None or pixels is not None or perturb is not None:

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "vpt_stream_kernels.hip.h"
+#include "vpt_implicit_kernel.hip.h"
 #include "vpt_kat_kernels.hip.h"
 #include <rocprim/rocprim.hpp>
 
@@ -217,7 +218,11 @@ struct vpt_scene {
   long long          spill_lanes = 0;
   // launch schedule of the mesh kernel (sched_cfg): per-wave cost of the last launch, waves by descending cost
   unsigned *d_cost = nullptr, *d_cost_sorted = nullptr;
-  int *     d_order = nullptr, *d_iota = nullptr;
+  int *     d_order = nullptr, *d_iota = nullptr, *d_next = nullptr;   // d_next: head of K2's pixel queue
+  hipEvent_t  ev_order = nullptr;       // recorded after the sort that writes d_order
+  hipStream_t order_stream = nullptr;   // the stream that sort ran on
+  int         k2_resident[2] = {0, 0};  // resident workgroups per CU of vpt_render_kernel<K_IMPLICIT / _NORMAL> (occupancy query)
+  int         num_cus = 0;
   void*     sort_temp = nullptr;
   size_t    sort_temp_bytes = 0;
   long long sched_waves = 0;       // waves the buffers are sized for
@@ -229,6 +234,7 @@ struct vpt_scene {
   long long  staged_pixels = 0, staged_slots = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool       timed = false;
+  unsigned*  d_watchdog = nullptr;   // waves of the implicit kernel that gave up (must stay 0; vpt_implicit_kernel.hip.h)
   // streaming pipeline (vpt_stream_kernels.hip.h): path state + ray queues, sized for `path_slots`
   DPaths     paths = {};
   long long  path_slots = 0;
@@ -408,9 +414,11 @@ void vpt_scene_destroy(vpt_scene* s) {
     if (p) (void)hipFree(p);
   for (void* p : s->path_allocs) (void)hipFree(p);
   if (s->spill) (void)hipFree(s->spill);
-  for (void* p : {(void*)s->d_cost, (void*)s->d_cost_sorted, (void*)s->d_order, (void*)s->d_iota, s->sort_temp})
+  for (void* p : {(void*)s->d_cost, (void*)s->d_cost_sorted, (void*)s->d_order, (void*)s->d_iota, (void*)s->d_next, s->sort_temp})
     if (p) (void)hipFree(p);
+  if (s->ev_order) (void)hipEventDestroy(s->ev_order);
   if (s->host_counts) (void)hipHostFree(s->host_counts);
+  if (s->d_watchdog) (void)hipFree(s->d_watchdog);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -700,6 +708,10 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   }
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
+  HIP_TRY(hipMalloc((void**)&s->d_watchdog, 4));
+  HIP_TRY(hipMemset(s->d_watchdog, 0, 4));
+  HIP_TRY(hipMalloc((void**)&s->d_next, 4));
+  HIP_TRY(hipEventCreateWithFlags(&s->ev_order, hipEventDisableTiming));
   HIP_TRY(hipDeviceSynchronize());
   *out = s;
   s    = nullptr;   // release the guard
@@ -831,7 +843,13 @@ static int sched_prepare(vpt_scene* s, long long waves, const long long key[10],
 static int sched_update(vpt_scene* s, long long waves, hipStream_t st) {
   size_t bytes = s->sort_temp_bytes;
   HIP_TRY(rocprim::radix_sort_pairs_desc(s->sort_temp, bytes, s->d_cost, s->d_cost_sorted, s->d_iota, s->d_order, (size_t)waves, 0, 32, st));
-  s->order_valid = true;
+  HIP_TRY(hipEventRecord(s->ev_order, st));
+  s->order_valid = true, s->order_stream = st;
+  return VPT_OK;
+}
+// d_order / d_cost are written on the stream of the previous launch: a launch on another stream waits for that sort
+static int sched_wait(vpt_scene* s, hipStream_t st) {
+  if (s->order_valid && s->order_stream != st) HIP_TRY(hipStreamWaitEvent(st, s->ev_order, 0));
   return VPT_OK;
 }
 
@@ -904,6 +922,7 @@ static int launch_mesh(const launch_ctx& L) {
   long long key[10];
   schedule_key(L, key);
   if (int rc = sched_prepare(s, L.grid.x, key, L.st)) return rc;
+  if (int rc = sched_wait(s, L.st)) return rc;
   size_t lds = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int);   // (ref, t0) pairs
   int n = L.pr.nsamples, pilot = n / 64 < 1 ? 1 : n / 64 > 16 ? 16 : n / 64;
   int parts[2] = {(!s->order_valid && n >= 16) ? pilot : n, 0};
@@ -921,17 +940,34 @@ static int launch_mesh(const launch_ctx& L) {
   }
   return VPT_OK;
 }
-// K2 (implicit shaders): same schedule, costs from the previous launch on this layout (no pilot)
+// K2 (implicit shaders): a fixed number of resident waves, pixels handed out from a queue, longest pixel first by the
+// trips each pixel took in the previous launch on this layout (identity order without such a record)
 template <int K>
 static int launch_implicit(const launch_ctx& L) {
   vpt_scene* s = L.s;
   long long key[10];
   schedule_key(L, key);
-  if (int rc = sched_prepare(s, L.grid.x, key, L.st)) return rc;
-  size_t    lds = (size_t)s->stack_cap * VPT_BLOCK * sizeof(int);   // refs only
-  sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost};
-  hipLaunchKernelGGL(vpt_render_kernel<K>, L.grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch);
-  return sched_update(s, L.grid.x, L.st);
+  if (int rc = sched_prepare(s, L.pr.nslots, key, L.st)) return rc;
+  if (int rc = sched_wait(s, L.st)) return rc;
+  size_t lds = (size_t)s->stack_cap * VPT_BLOCK * sizeof(int);   // refs only
+  int&   resident = s->k2_resident[K == K_IMPLICIT ? 0 : 1];
+  if (resident == 0) {
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, vpt_render_kernel<K>, VPT_BLOCK, lds));
+    if (resident < 1) resident = 1;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+    s->num_cus = prop.multiProcessorCount;
+  }
+  long long waves = ((long long)L.pr.nslots + VPT_BLOCK - 1) / VPT_BLOCK, persistent = (long long)resident * s->num_cus;
+  if (const char* e = getenv("VPT_K2_GRID")) {   // tuning experiments: waves per CU (0: one wave per 64 slots, as K1)
+    int per_cu = atoi(e);
+    persistent = per_cu > 0 ? (long long)per_cu * s->num_cus : waves;
+  }
+  dim3 grid((unsigned)(waves < persistent ? waves : persistent));
+  HIP_TRY(hipMemsetAsync(s->d_next, 0, 4, L.st));
+  sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, s->d_next, L.pr.nslots};
+  hipLaunchKernelGGL(vpt_render_kernel<K>, grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog);
+  return sched_update(s, L.pr.nslots, L.st);
 }
 
 
@@ -975,12 +1011,20 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
   return VPT_OK;
 }
 
+// synchronous: waves of the implicit kernel that hit their watchdog since the scene was created (a defect, never a workload)
+static int check_watchdog(vpt_scene* s) {
+  unsigned n = 0;
+  HIP_TRY(hipMemcpy(&n, s->d_watchdog, 4, hipMemcpyDeviceToHost));
+  if (n) return fail(VPT_ERR_HIP, "%u wave(s) of the implicit kernel gave up after their watchdog time: the result is incomplete", n);
+  return VPT_OK;
+}
+
 int vpt_last_kernel_ms(vpt_scene* s, float* ms) {
   if (!s || !ms) return fail(VPT_ERR_INVALID_ARG, "null argument");
   if (!s->timed) return fail(VPT_ERR_INVALID_ARG, "no launch recorded");
   HIP_TRY(hipEventSynchronize(s->ev1));
   HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
-  return VPT_OK;
+  return check_watchdog(s);
 }
 
 int vpt_resolve_device(const vpt_layout* layout, const void* d_tiles_all_ranks, int samples, void* d_image_rowmajor, void* stream) {
@@ -1034,6 +1078,7 @@ int vpt_render(vpt_scene* s, const vpt_params* params, int nsamples, int width, 
   if (int rc = vpt_state_upload(&lay, image_rgba, hits, rng, s->s_image, s->s_hits, s->s_rng, nullptr)) return rc;
   if (int rc = vpt_render_device(s, params, &lay, todo, s->s_image, s->s_hits, s->s_rng, nullptr)) return rc;
   if (int rc = vpt_state_download(&lay, s->s_image, s->s_hits, s->s_rng, image_rgba, hits, rng, nullptr)) return rc;
+  if (int rc = check_watchdog(s)) return rc;
   *samples_io += todo;
   return VPT_OK;
 }

@@ -4,7 +4,7 @@
 // production code itself.  Record layouts: include/vpt_kat.h.
 #pragma once
 #include "vpt_kat.h"
-#include "vpt_mesh_kernel.hip.h"
+#include "vpt_implicit_kernel.hip.h"
 
 VPT_DEV void kat_put3(float* o, f3 v) { o[0] = v.x, o[1] = v.y, o[2] = v.z; }
 
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_kat_kernel(
     case VPT_KAT_ENVIRONMENT: kat_put3(o, eval_environment(sc, ld3(a))); break;
     case VPT_KAT_SAMPLE_LIGHTS: kat_put3(o, sample_lights(sc, ld3(a), a[3], a[4], mk2(a[5], a[6]))); break;
     case VPT_KAT_LIGHTS_PDF: o[0] = kat_lights_pdf_k1(sc, ld3(a), ld3(a + 3), iparam, stk4); break;
-    case VPT_KAT_LIGHTS_PDF_K2: o[0] = sample_lights_pdf(sc, ld3(a), ld3(a + 3), iparam, stk2); break;
+    case VPT_KAT_LIGHTS_PDF_K2: o[0] = lights_pdf_k2(sc, ld3(a), ld3(a + 3), iparam, stk2); break;
     case VPT_KAT_SDF_SCENE: {
       sdf_hit r = eval_sdf_scene(sc, ld3(a), a[3]);
       o[0] = r.result, o[1] = (float)r.instance, o[2] = (float)r.sdf;
@@ -117,9 +117,17 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_kat_kernel(
       kat_put3(o, nrm);
     } break;
     case VPT_KAT_SPHERETRACE: {
-      int    sdf = (int)a[6];
-      st_hit h   = sdf < 0 ? spheretrace(sc, make_ray(ld3(a), ld3(a + 3)), iparam) : spheretrace_one(sc, ld3(a), ld3(a + 3), sdf, iparam);
-      o[0] = h.hit ? 1.0f : 0.0f, o[1] = h.dist, o[2] = (float)h.instance, o[3] = (float)h.sdf;
+      int sdf = (int)a[6];
+      if (sdf < 0) {   // the whole-scene form as K2 runs it: scene_march_step until the march ends
+        float t = VPT_RAY_EPS;
+        int   it = 0, inst = -1, fn = -1, mode;
+        do mode = scene_march_step(sc, ld3(a), ld3(a + 3), iparam, t, it, inst, fn);
+        while (mode == M_SCENE);
+        o[0] = mode == M_HIT ? 1.0f : 0.0f, o[1] = mode == M_HIT ? t : VPT_FLT_MAX, o[2] = (float)inst, o[3] = (float)fn;
+      } else {         // the single-SDF form (K1's SDF-light pdf; K2's is covered by VPT_KAT_LIGHTS_PDF_K2)
+        st_hit h = spheretrace_one(sc, ld3(a), ld3(a + 3), sdf, iparam);
+        o[0] = h.hit ? 1.0f : 0.0f, o[1] = h.dist, o[2] = (float)h.instance, o[3] = (float)h.sdf;
+      }
     } break;
     case VPT_KAT_VOLUME: o[0] = eval_volume(sc, sc.volumes[(int)a[0]], ld3(a + 1)); break;
     case VPT_KAT_SDF_FUNCTION: o[0] = eval_sdf_function(sc.sdfs[(int)a[0]], ld3(a + 1)); break;

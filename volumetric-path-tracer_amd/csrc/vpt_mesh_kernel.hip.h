@@ -431,6 +431,24 @@ VPT_DEV float other_light_pdf(const DScene& sc, int light_id, int kind, float4 r
   return 0;
 }
 
+// sample_lights_pdf's mesh-light walk (yocto_pathtrace.cpp:359-380) for an emissive mesh with a real BVH;
+// binary-node form with a refs-only LDS stack, for the kernels that do not carry the quad-node traversal (K2, the
+// stream pipeline's shade kernel)
+VPT_DEV float general_light_pdf(const DScene& sc, const vpt_light& light, f3 position, f3 direction, const lane_stack& stk) {
+  const DInstance& inst = sc.instances[light.instance];
+  float area = sc.light_cdf[light.cdf_offset + light.cdf_len - 1];
+  float lpdf = 0.0f;
+  f3    next_position = position;
+  for (int hop = 0; hop < 100; hop++) {
+    hit_t h = trace_instance(sc, light.instance, next_position, direction, stk);
+    if (!h.hit) break;
+    f3 lposition = eval_position(sc, inst, h.element, h.uv);
+    f3 lnormal   = eval_element_normal(sc, inst, h.element);
+    lpdf += distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * area);
+    next_position = lposition + direction * 1e-3f;
+  }
+  return lpdf;
+}
 // one hop of the same walk for an emissive mesh with a real BVH (yocto_pathtrace.cpp:363-378): `h` is the hit of the
 // single-instance query from the walk's current position; returns the hop's pdf term and moves the walk on
 VPT_DEV float large_light_hop(const DScene& sc, int light_id, const hit_t& h, f3 position, f3 direction, f3& next_position) {

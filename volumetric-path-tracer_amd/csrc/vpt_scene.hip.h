@@ -985,19 +985,7 @@ VPT_DEV st_hit spheretrace_one(const DScene& sc, f3 ro, f3 rd, int sdf_handle, i
   }
   return r;
 }
-VPT_DEV st_hit spheretrace(const DScene& sc, const ray_t& ray, int maxiter) {   // cpp:289-307
-  st_hit r = {false, VPT_FLT_MAX, -1, -1};
-  float  t = ray.tmin;
-  for (int i = 0; i < maxiter && t < ray.tmax; ++i) {
-    sdf_hit res = eval_sdf_scene(sc, ray_point(ray, t), t);
-    if (fabs_(res.result) < (VPT_FLT_EPS * t)) {
-      r.hit = true, r.dist = t, r.instance = res.instance, r.sdf = res.sdf;
-      return r;
-    }
-    t += res.result;
-  }
-  return r;
-}
+// spheretrace(scene, ray, maxiter) (cpp:289-307) is K2's scene_march_step (vpt_implicit_kernel.hip.h), one step per trip
 
 // ------------------------------------------------------------------------------------------------
 // lights, yocto_pathtrace.cpp:312-421
@@ -1042,50 +1030,5 @@ VPT_DEV f3 sample_lights(const DScene& sc, f3 position, float rl, float rel, f2 
   }
   return mk3(0, 0, 0);
 }
-VPT_DEV float sample_lights_pdf(const DScene& sc, f3 position, f3 direction, int maxiter, const lane_stack& stk) {
-  float pdf = 0.0f;
-  for (int l = 0; l < sc.num_lights; l++) {
-    const vpt_light&    light = sc.lights[l];
-    const float* cdf   = sc.light_cdf + light.cdf_offset;
-    if (light.instance != VPT_INVALID) {
-      const DInstance& inst = sc.instances[light.instance];
-      float area = cdf[light.cdf_len - 1];
-      float lpdf = 0.0f;
-      f3    next_position = position;
-      for (int bounce = 0; bounce < 100; bounce++) {
-        hit_t h = trace_instance(sc, light.instance, next_position, direction, stk);
-        if (!h.hit) break;
-        f3 lposition = eval_position(sc, inst, h.element, h.uv);
-        f3 lnormal   = eval_element_normal(sc, inst, h.element);
-        lpdf += distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * area);
-        next_position = lposition + direction * 1e-3f;
-      }
-      pdf += lpdf;
-    } else if (light.sdf != VPT_INVALID) {
-      st_hit h = spheretrace_one(sc, position, direction, light.sdf, maxiter);
-      if (h.hit) {
-        f3 lposition = position + direction * h.dist;
-        f3 lnormal   = eval_sdf_normal_function(sc.sdfs[h.sdf], position, h.dist);   // (sic) at `position`, cpp:389
-        float area   = cdf[light.cdf_len - 1];
-        pdf += distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * area);
-      }
-    } else if (light.environment != VPT_INVALID) {
-      const vpt_environment& env = sc.environments[light.environment];
-      if (env.emission_tex != VPT_INVALID) {
-        int tw = sc.textures[env.emission_tex].width, th = sc.textures[env.emission_tex].height;
-        f3 wl = transform_direction(load_frame(sc.env_inv + 3 * light.environment), direction);
-        f2 tc = mk2(atan2f(wl.z, wl.x) / (2 * VPT_PI), acosf(clampf(wl.y, -1.0f, 1.0f)) / VPT_PI);
-        if (tc.x < 0) tc.x += 1;
-        int i = clampi((int)(tc.x * tw), 0, tw - 1), j = clampi((int)(tc.y * th), 0, th - 1);
-        int idx = j * tw + i;
-        float prob  = (idx == 0 ? cdf[0] : cdf[idx] - cdf[idx - 1]) / cdf[light.cdf_len - 1];
-        float angle = (2 * VPT_PI / tw) * (VPT_PI / th) * sinf(VPT_PI * (j + 0.5f) / th);
-        pdf += prob / angle;
-      } else {
-        pdf += 1 / (4 * VPT_PI);
-      }
-    }
-  }
-  pdf *= (float)1 / (float)sc.num_lights;
-  return pdf;
-}
+// sample_lights_pdf (yocto_pathtrace.cpp:353-421) is evaluated per light from the light records: small_light_pdf /
+// general_light_pdf / other_light_pdf in vpt_mesh_kernel.hip.h, the SDF-light march of K2 in vpt_implicit_kernel.hip.h.

@@ -162,23 +162,6 @@ __global__ void __launch_bounds__(VPT_BLOCK, 4) vpt_stream_trace(DScene sc, DPat
   P.hit_t[slot] = h.distance;
 }
 
-// sample_lights_pdf's mesh-light walk (yocto_pathtrace.cpp:359-380) for an emissive mesh with a real BVH;
-// only reached by scenes that have such lights (the shade kernel then gets an LDS stack)
-VPT_DEV float general_light_pdf(const DScene& sc, const vpt_light& light, f3 position, f3 direction, const lane_stack& stk) {
-  const DInstance& inst = sc.instances[light.instance];
-  float area = sc.light_cdf[light.cdf_offset + light.cdf_len - 1];
-  float lpdf = 0.0f;
-  f3    next_position = position;
-  for (int hop = 0; hop < 100; hop++) {
-    hit_t h = trace_instance(sc, light.instance, next_position, direction, stk);
-    if (!h.hit) break;
-    f3 lposition = eval_position(sc, inst, h.element, h.uv);
-    f3 lnormal   = eval_element_normal(sc, inst, h.element);
-    lpdf += distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * area);
-    next_position = lposition + direction * 1e-3f;
-  }
-  return lpdf;
-}
 VPT_DEV float lights_pdf(const DScene& sc, const DParams& pr, f3 position, f3 direction, const lane_stack& stk) {
   float pdf = 0.0f;   // sample_lights_pdf, yocto_pathtrace.cpp:353-421
   for (int l = 0; l < sc.num_lights; l++) {

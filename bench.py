@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--strong", action="store_true", help="fixed 1280-wide frame for every N")
     ap.add_argument("--cpu-sample", default="640x96", help="cpu baseline sample: <resolution>x<spp>; '0' disables")
     ap.add_argument("--tile", type=int, default=8)
+    ap.add_argument("--balance", action="store_true", help="add per-wave duration statistics of the last launch to the line")
     args = ap.parse_args()
 
     import numpy as np
@@ -129,6 +130,12 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
+    balance = None
+    if args.balance:   # load-balance figures of the last launch (after the timed region): per-wave durations
+        c = dev.last_wave_costs().astype(np.float64) * 1e-5   # ticks of 100 MHz -> ms
+        c = c[c > 0]
+        balance = {"waves": int(len(c)), "longest_wave_ms": round(float(c.max()), 3), "mean_wave_ms": round(float(c.mean()), 4),
+                   "sum_wave_ms": round(float(c.sum()), 1), "p99_wave_ms": round(float(np.quantile(c, 0.99)), 3)}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -204,6 +211,8 @@ def main():
                        "samples_per_step": samples_per_step},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if balance:
+            line["balance"] = balance
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

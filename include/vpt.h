@@ -285,6 +285,12 @@ int vpt_resolve_srgb8_device(const vpt_layout* layout, const void* d_tiles_all_r
  * that has not finished after 300 s leaves the kernel instead of holding the GPU: a defect, never a workload). */
 int vpt_last_kernel_ms(vpt_scene* scene, float* ms);
 
+/* How long every wave of the last vpt_render_device launch on this scene ran, in ticks of the 100 MHz wall clock,
+ * indexed by wave (wave w renders state slots 64 w .. 64 w + 63): what the next launch's longest-first order is made
+ * from, exposed for load-balance analysis (critical path = the largest entry, work = their sum).  Synchronises with the
+ * launch.  *count = waves of the launch; at most `capacity` entries are written. */
+int vpt_last_wave_costs(vpt_scene* scene, unsigned* ticks, int capacity, int* count);
+
 /* intersect_bvh(bvh, scene, ray) (instance < 0) / intersect_bvh(bvh, scene, instance, ray) of yocto_bvh.h, for a
  * batch of `n` host rays {o.xyz, d.xyz} with the reference's default tmin = 1e-4, tmax = flt_max, through the
  * kernels' own traversal.  ids[2i..] = {instance, element} (-1, -1 on a miss), uvt[3i..] = {u, v, distance}.

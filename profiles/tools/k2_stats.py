@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Where the lanes of K2's waves are, trip by trip (diagnostic build -DVPT_K2_STATS of libvpt_hip.so):
+    VPT_HIP_LIB=variants/libvpt_hip_k2stats.so python profiles/tools/k2_stats.py [scene.json] [spp]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import vpt_loader  # noqa: E402
+
+NAMES = ("trips scene_rounds scene_lanes light_rounds light_lanes shade_rounds shade_lanes done_lanes wait_lanes_at_march "
+         "light_lanes_at_scene scene_lanes_at_shade").split()
+
+
+def main():
+    vpt = vpt_loader.load()
+    scene_file = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests/golden/scenes/06_gridsdf_synth/gridsdf_synth.json")
+    spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    scene = vpt.HostScene(scene_file)
+    dev = vpt.DeviceScene(scene, 0)
+    p = vpt.PathtraceParams(resolution=1280, samples=1 << 20, shader="implicit", bounces=4)
+    st = scene.make_state(p)
+    dev.pathtrace_samples(st, p, spp)          # first launch: tile order
+    out = (C.c_ulonglong * 16)()
+    vpt.hip.vpt_debug_k2_stats(out, 1)
+    dev.pathtrace_samples(st, p, spp)          # second launch: longest wave first
+    vpt.hip.vpt_debug_k2_stats(out, 0)
+    v = dict(zip(NAMES, list(out)))
+    print({k: x for k, x in v.items()})
+    print(f"lanes per scene round {v['scene_lanes'] / max(1, v['scene_rounds']):.1f}, per light round {v['light_lanes'] / max(1, v['light_rounds']):.1f}, "
+          f"per shading round {v['shade_lanes'] / max(1, v['shade_rounds']):.1f}")
+    print(f"per trip: done lanes {v['done_lanes'] / v['trips']:.1f}, waiting at march trips {v['wait_lanes_at_march'] / max(1, v['trips'] - v['shade_rounds']):.1f}, "
+          f"light lanes during scene rounds {v['light_lanes_at_scene'] / max(1, v['scene_rounds']):.1f}, marching lanes parked during shading {v['scene_lanes_at_shade'] / max(1, v['shade_rounds']):.1f}")
+    print(f"rounds: trips {v['trips']}, scene {v['scene_rounds']}, light {v['light_rounds']}, shade {v['shade_rounds']}")
+
+
+if __name__ == "__main__":
+    main()

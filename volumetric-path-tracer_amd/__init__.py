@@ -101,6 +101,7 @@ hip.vpt_render_device.argtypes = [_p, C.POINTER(VptParams), C.POINTER(VptLayout)
 hip.vpt_resolve_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
 hip.vpt_last_kernel_ms.argtypes = [_p, C.POINTER(C.c_float)]
 hip.vpt_intersect.argtypes = [_p, C.c_int, _p, C.c_int, _p, _p]
+hip.vpt_last_wave_costs.argtypes = [_p, _p, C.c_int, C.POINTER(C.c_int)]
 hip.vpt_resolve_srgb8_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
 hip.vpt_selftest_reciprocal.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
 hip.vpt_selftest_light_cdf.argtypes = [_p, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
@@ -239,6 +240,14 @@ class DeviceScene:
         ms = C.c_float()
         _check(hip.vpt_last_kernel_ms(self.handle, C.byref(ms)), "vpt_last_kernel_ms")
         return ms.value
+
+    def last_wave_costs(self) -> np.ndarray:
+        """ticks (100 MHz) every wave of the last launch ran, indexed by wave (include/vpt.h)"""
+        n = C.c_int(0)
+        _check(hip.vpt_last_wave_costs(self.handle, None, 0, C.byref(n)), "vpt_last_wave_costs")
+        out = np.zeros(n.value, np.uint32)
+        _check(hip.vpt_last_wave_costs(self.handle, out.ctypes.data, n.value, C.byref(n)), "vpt_last_wave_costs")
+        return out
 
     def close(self) -> None:
         if getattr(self, "handle", None) and hip is not None:   # see HostScene.close

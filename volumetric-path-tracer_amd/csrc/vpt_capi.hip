@@ -218,11 +218,10 @@ struct vpt_scene {
   long long          spill_lanes = 0;
   // launch schedule of the mesh kernel (sched_cfg): per-wave cost of the last launch, waves by descending cost
   unsigned *d_cost = nullptr, *d_cost_sorted = nullptr;
-  int *     d_order = nullptr, *d_iota = nullptr, *d_next = nullptr;   // d_next: head of K2's pixel queue
+  int *     d_order = nullptr, *d_iota = nullptr;
   hipEvent_t  ev_order = nullptr;       // recorded after the sort that writes d_order
   hipStream_t order_stream = nullptr;   // the stream that sort ran on
-  int         k2_resident[2] = {0, 0};  // resident workgroups per CU of vpt_render_kernel<K_IMPLICIT / _NORMAL> (occupancy query)
-  int         num_cus = 0;
+
   void*     sort_temp = nullptr;
   size_t    sort_temp_bytes = 0;
   long long sched_waves = 0;       // waves the buffers are sized for
@@ -414,7 +413,7 @@ void vpt_scene_destroy(vpt_scene* s) {
     if (p) (void)hipFree(p);
   for (void* p : s->path_allocs) (void)hipFree(p);
   if (s->spill) (void)hipFree(s->spill);
-  for (void* p : {(void*)s->d_cost, (void*)s->d_cost_sorted, (void*)s->d_order, (void*)s->d_iota, (void*)s->d_next, s->sort_temp})
+  for (void* p : {(void*)s->d_cost, (void*)s->d_cost_sorted, (void*)s->d_order, (void*)s->d_iota, s->sort_temp})
     if (p) (void)hipFree(p);
   if (s->ev_order) (void)hipEventDestroy(s->ev_order);
   if (s->host_counts) (void)hipHostFree(s->host_counts);
@@ -690,6 +689,109 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   UP(upload(s, d.vol_instances, d.num_vol_instances, &D.vol_instances));
   UP(upload(s, d.sdfs, d.num_sdfs, &D.sdfs));
   UP(upload(s, sdf_inv, &D.sdf_inv));
+  {
+    // SDF evaluation records (vpt_scene.hip.h "SDF records") and the balls the escaping-ray early-out needs.  The
+    // constants are folded with the reference's own float operations (yocto_sdfs.cpp:33-38, yocto_sceneio.cpp:3697);
+    // the balls are test-independent geometry, computed in double with a 5 % margin.  Only rigid frames get a ball
+    // (a scaling frame turns SDF values into something other than world distances): radius -1 switches the early-out off.
+    auto rigid = [](const vpt_frame& f) {
+      double c[3][3] = {{f.x[0], f.x[1], f.x[2]}, {f.y[0], f.y[1], f.y[2]}, {f.z[0], f.z[1], f.z[2]}};
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+          double dp = c[i][0] * c[j][0] + c[i][1] * c[j][1] + c[i][2] * c[j][2];
+          if (std::fabs(dp - (i == j ? 1.0 : 0.0)) > 1e-5) return false;
+        }
+      return true;
+    };
+    auto identity3 = [](const vpt_frame& f) {
+      return f.x[0] == 1 && f.x[1] == 0 && f.x[2] == 0 && f.y[0] == 0 && f.y[1] == 1 && f.y[2] == 0 && f.z[0] == 0 && f.z[1] == 0 && f.z[2] == 1;
+    };
+    // world position of a local point: the SDFs apply the FORWARD frame to world points (yocto_sdfs.cpp:13), so world = R^T (local - o)
+    auto to_world = [](const vpt_frame& f, const double l[3], double w[3]) {
+      double v[3] = {l[0] - f.o[0], l[1] - f.o[1], l[2] - f.o[2]};
+      w[0] = f.x[0] * v[0] + f.y[0] * v[1] + f.z[0] * v[2];   // rows of R^T = the frame's x, y, z taken component-wise
+      w[1] = f.x[1] * v[0] + f.y[1] * v[1] + f.z[1] * v[2];
+      w[2] = f.x[2] * v[0] + f.y[2] * v[1] + f.z[2] * v[2];
+    };
+    struct ball { double c[3], r; };
+    std::vector<ball> balls;
+    bool all_bounded_rigid = true;
+    int  planes = 0;
+    std::vector<float4> fn_rec(6 * (size_t)d.num_sdfs, make_float4(0, 0, 0, 0)), grid_rec(7 * (size_t)d.num_vol_instances, make_float4(0, 0, 0, 0));
+    for (int i = 0; i < d.num_sdfs; i++) {
+      const vpt_sdf& f = d.sdfs[i];
+      float4* r = &fn_rec[6 * (size_t)i];
+      pack_frame(to_h(f.frame), r);
+      r[3] = make_float4(f.p[0], f.p[1], f.p[2], f.p[3]);
+      r[4] = make_float4(f.whd[0] * 0.5f, f.whd[1] * 0.5f, f.whd[2] * 0.5f, 0);
+      int tag = f.type | ((identity3(f.frame) ? 1 : 0) << 8);
+      memcpy(&r[4].w, &tag, 4);
+      double lc[3] = {0, 0, 0}, lr = -1;   // local centre / radius of a ball around the shape
+      switch (f.type) {
+        case VPT_SDF_BOX: lc[0] = f.whd[0] * 0.5, lc[1] = f.whd[1] * 0.5, lc[2] = f.whd[2] * 0.5, lr = std::sqrt(lc[0] * lc[0] + lc[1] * lc[1] + lc[2] * lc[2]); break;
+        case VPT_SDF_BBOX: lr = std::sqrt((double)f.p[1] * f.p[1] + (double)f.p[2] * f.p[2] + (double)f.p[3] * f.p[3]) + 2.0 * std::fabs((double)f.p[0]); break;
+        case VPT_SDF_SPHERE: lr = std::fabs((double)f.p[0]); break;
+        case VPT_SDF_TORUS: lr = std::fabs((double)f.p[0]) + std::fabs((double)f.p[1]); break;
+        case VPT_SDF_CAPPED_CONE: lr = std::sqrt((double)f.p[0] * f.p[0] + std::max((double)f.p[1] * f.p[1], (double)f.p[2] * f.p[2])); break;
+        default: break;   // plane: unbounded
+      }
+      r[5] = make_float4(0, 0, 0, -1);
+      if (f.type == VPT_SDF_PLANE) planes++;
+      else if (lr > 0 && std::isfinite(lr) && rigid(f.frame)) {
+        ball b;
+        to_world(f.frame, lc, b.c);
+        b.r = lr * 1.05 + 1e-6;
+        balls.push_back(b);
+        r[5] = make_float4((float)b.c[0], (float)b.c[1], (float)b.c[2], (float)b.r);
+      } else all_bounded_rigid = false;
+    }
+    for (int i = 0; i < d.num_vol_instances; i++) {
+      const vpt_volume_instance& vi = d.vol_instances[i];
+      const vpt_volume&          vol = d.volumes[vi.volume];
+      float4* r = &grid_rec[7 * (size_t)i];
+      pack_frame(to_h(vi.frame), r);
+      // bbox_max = origin + (vol.res * grid_res) * scalef; bbox_size = bbox_max - origin   (yocto_sdfs.cpp:33-36, float)
+      float size[3];
+      for (int k = 0; k < 3; k++) {
+        float origin = vi.frame.o[k], grid_res = (float)vol.whd[k];
+        float bbox_max = origin + (vol.res * grid_res) * vi.scalef;
+        size[k] = bbox_max - origin;
+      }
+      r[3] = make_float4(size[0], size[1], size[2], vi.scalef);
+      r[4] = make_float4(size[0] * 0.5f, size[1] * 0.5f, size[2] * 0.5f, 0);
+      int tr = identity3(vi.frame) ? 1 : 0;
+      memcpy(&r[4].w, &tr, 4);
+      int dims[3] = {vol.whd[0], vol.whd[1], vol.whd[2]};
+      memcpy(&r[5], dims, 12);
+      r[5].w = vol.res;
+      int off[2] = {(int)(vol.offset & 0xffffffffll), (int)(vol.offset >> 32)};
+      memcpy(&r[6], off, 8);
+      double lc[3] = {size[0] * 0.5, size[1] * 0.5, size[2] * 0.5}, lr = std::sqrt(lc[0] * lc[0] + lc[1] * lc[1] + lc[2] * lc[2]);
+      if (lr > 0 && std::isfinite(lr) && rigid(vi.frame)) {
+        ball b;
+        to_world(vi.frame, lc, b.c);
+        b.r = lr * 1.05 + 1e-6;
+        balls.push_back(b);
+      } else all_bounded_rigid = false;
+    }
+    D.sdf_bound_cx = D.sdf_bound_cy = D.sdf_bound_cz = 0, D.sdf_bound_r = -1, D.sdf_num_planes = planes;
+    if (all_bounded_rigid && !balls.empty()) {
+      double c[3] = {0, 0, 0}, rr = 0;
+      for (const ball& b : balls)
+        for (int k = 0; k < 3; k++) c[k] += b.c[k] / (double)balls.size();
+      for (const ball& b : balls) {
+        double dist = std::sqrt((b.c[0] - c[0]) * (b.c[0] - c[0]) + (b.c[1] - c[1]) * (b.c[1] - c[1]) + (b.c[2] - c[2]) * (b.c[2] - c[2]));
+        rr = std::max(rr, dist + b.r);
+      }
+      D.sdf_bound_cx = (float)c[0], D.sdf_bound_cy = (float)c[1], D.sdf_bound_cz = (float)c[2], D.sdf_bound_r = (float)(rr * 1.01);
+    }
+    if (getenv("VPT_NO_EARLY_OUT")) {   // A/B switch for the experiments of DESIGN.md: the marches then run to the reference's own end
+      D.sdf_bound_r = -1;
+      for (int i = 0; i < d.num_sdfs; i++) fn_rec[6 * (size_t)i + 5].w = -1;
+    }
+    UP(upload(s, fn_rec, &D.sdf_fn_rec));
+    UP(upload(s, grid_rec, &D.sdf_grid_rec));
+  }
   UP(upload(s, d.cameras, d.num_cameras, &D.cameras));
 #undef UP
   {
@@ -710,7 +812,6 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   HIP_TRY(hipEventCreate(&s->ev1));
   HIP_TRY(hipMalloc((void**)&s->d_watchdog, 4));
   HIP_TRY(hipMemset(s->d_watchdog, 0, 4));
-  HIP_TRY(hipMalloc((void**)&s->d_next, 4));
   HIP_TRY(hipEventCreateWithFlags(&s->ev_order, hipEventDisableTiming));
   HIP_TRY(hipDeviceSynchronize());
   *out = s;
@@ -940,34 +1041,20 @@ static int launch_mesh(const launch_ctx& L) {
   }
   return VPT_OK;
 }
-// K2 (implicit shaders): a fixed number of resident waves, pixels handed out from a queue, longest pixel first by the
-// trips each pixel took in the previous launch on this layout (identity order without such a record)
+// K2 (implicit shaders): same schedule, costs from the previous launch on this layout (no pilot)
 template <int K>
 static int launch_implicit(const launch_ctx& L) {
   vpt_scene* s = L.s;
   long long key[10];
   schedule_key(L, key);
-  if (int rc = sched_prepare(s, L.pr.nslots, key, L.st)) return rc;
+  if (int rc = sched_prepare(s, L.grid.x, key, L.st)) return rc;
   if (int rc = sched_wait(s, L.st)) return rc;
-  size_t lds = (size_t)s->stack_cap * VPT_BLOCK * sizeof(int);   // refs only
-  int&   resident = s->k2_resident[K == K_IMPLICIT ? 0 : 1];
-  if (resident == 0) {
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, vpt_render_kernel<K>, VPT_BLOCK, lds));
-    if (resident < 1) resident = 1;
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-    s->num_cus = prop.multiProcessorCount;
-  }
-  long long waves = ((long long)L.pr.nslots + VPT_BLOCK - 1) / VPT_BLOCK, persistent = (long long)resident * s->num_cus;
-  if (const char* e = getenv("VPT_K2_GRID")) {   // tuning experiments: waves per CU (0: one wave per 64 slots, as K1)
-    int per_cu = atoi(e);
-    persistent = per_cu > 0 ? (long long)per_cu * s->num_cus : waves;
-  }
-  dim3 grid((unsigned)(waves < persistent ? waves : persistent));
-  HIP_TRY(hipMemsetAsync(s->d_next, 0, 4, L.st));
-  sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, s->d_next, L.pr.nslots};
-  hipLaunchKernelGGL(vpt_render_kernel<K>, grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog);
-  return sched_update(s, L.pr.nslots, L.st);
+  size_t    lds = (size_t)s->stack_cap * VPT_BLOCK * sizeof(int) +                                      // refs-only stack
+               (6 * (size_t)s->d.num_sdfs + 7 * (size_t)s->d.num_vol_instances) * sizeof(float4);       // the SDF records
+  if (lds > 64 * 1024) return fail(VPT_ERR_UNSUPPORTED, "scene has too many SDFs for the implicit kernel's LDS copy of their records (%d + %d)", s->d.num_sdfs, s->d.num_vol_instances);
+  sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost};
+  hipLaunchKernelGGL(vpt_render_kernel<K>, L.grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog);
+  return sched_update(s, L.grid.x, L.st);
 }
 
 
@@ -1008,6 +1095,18 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev1, st));
   s->timed = true;
+  return VPT_OK;
+}
+
+int vpt_last_wave_costs(vpt_scene* s, unsigned* ticks, int capacity, int* count) {
+  if (!s || !count || capacity < 0 || (capacity > 0 && !ticks)) return fail(VPT_ERR_INVALID_ARG, "bad argument");
+  if (!s->timed) return fail(VPT_ERR_INVALID_ARG, "no launch recorded");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventSynchronize(s->ev1));
+  long long n = s->sched_key[0] / VPT_BLOCK;   // waves of the last launch's layout (sched_key[0] = its state slots)
+  *count = (int)n;
+  if (n > capacity) n = capacity;
+  if (n > 0) HIP_TRY(hipMemcpy(ticks, s->d_cost, (size_t)n * 4, hipMemcpyDeviceToHost));
   return VPT_OK;
 }
 
@@ -1226,6 +1325,18 @@ int vpt_selftest_light_cdf(vpt_scene* s, int light, int n, unsigned long long* m
 #ifdef VPT_WAVE_TIMES
 int vpt_debug_wave_times(unsigned long long* out, int nwaves) {
   HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vpt_wave_times), sizeof(unsigned long long) * 2 * (size_t)nwaves));
+  return VPT_OK;
+}
+#endif
+
+#ifdef VPT_K2_STATS
+// diagnostic build only: read (and optionally clear) K2's lane statistics (vpt_implicit_kernel.hip.h)
+int vpt_debug_k2_stats(unsigned long long* out16, int reset) {
+  if (out16) HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_k2_stats), sizeof(unsigned long long) * 16));
+  if (reset) {
+    unsigned long long zero[16] = {};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_k2_stats), zero, sizeof(zero)));
+  }
   return VPT_OK;
 }
 #endif

@@ -131,6 +131,13 @@ struct DScene {
   const vpt_volume_instance* vol_instances;
   const vpt_sdf*             sdfs;
   const float4*              sdf_inv;   // 3 float4 per sdf: inverse(frame) (rigid), for light sampling
+  // SDF evaluation records (layout: vpt_scene.hip.h, "SDF records"): 6 float4 per analytic SDF, 7 per voxel-grid instance
+  const float4*              sdf_fn_rec;
+  const float4*              sdf_grid_rec;
+  // ball around everything bounded the SDF shaders can hit (grids' boxes, all analytic SDFs but planes), world space;
+  // sdf_bound_r <= 0: no early-out for escaping rays.  sdf_num_planes: analytic SDFs of unbounded type
+  float sdf_bound_cx, sdf_bound_cy, sdf_bound_cz, sdf_bound_r;
+  int   sdf_num_planes, pad3;
   const vpt_camera*          cameras;
 };
 

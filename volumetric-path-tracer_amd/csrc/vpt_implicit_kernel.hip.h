@@ -22,53 +22,95 @@
 // across lanes changed.  The MIS light-pdf loop over the lights (cpp:353-421) is resumable like K1's: mesh and
 // environment lights are evaluated inline from the light records, an SDF light hands the lane to M_LIGHT.
 //
-// Pixels are handed out DYNAMICALLY.  A pixel's cost varies by two orders of magnitude (sky: one short march per
-// sample; floor towards the horizon: several 450-step marches), and with one fixed pixel per lane a wave's lanes ran
-// out of work one after another: 36 % of the VALU lanes worked (profiles/r02_k2_v2_*).  Now the launch is a fixed
-// number of resident waves and a lane that has finished its pixel's samples writes the pixel's state back and takes
-// the next pixel from a queue (one wave-aggregated atomic per batch of fetching lanes), longest pixel first: every
-// pixel records how many trips it kept its lane busy, and the host sorts the queue by that for the next launch on the
-// same layout.  A pixel still belongs to exactly one lane for all its samples, so results are unchanged.
+// Tried and not kept: handing pixels out dynamically (a fixed number of resident waves, a lane that has finished its
+// pixel takes the next one from a queue, longest pixel first).  121 Msamples/s against 131 with one fixed pixel per lane
+// and the longest-wave-first launch order: the launch is bound by its heaviest PIXELS — a floor pixel near the horizon
+// marches ~700 dependent steps per sample, 128 samples in sequence, ~0.5 s of the 0.67 s launch — not by idle lanes,
+// and neighbouring pixels in one wave march alike, which the queue gives up.  What shortens that chain is a cheaper
+// step (SDF records with the per-evaluation constants folded, three additions for translation-only frames) and fewer
+// steps: a march that can only end in a miss — the ray has left the ball around everything it could hit and recedes
+// from it — ends at once (march_cannot_hit, vpt_scene.hip.h; the reference spends ~130 doublings of t on each).
+// Also tried and not kept: skipping, per lane, the SDFs whose last value minus the distance marched since (they are
+// 1-Lipschitz) still exceeds an upper bound of the scene minimum — exact, five of six SDFs skipped on a floor-grazing
+// march — 166 against 174 Msamples/s: a wave evaluates an SDF as soon as ONE lane needs it, and the table costs more
+// than the few whole-wave skips save (longest wave 388 against 413 ms, but the mean wave 169 against 161 ms).
 #pragma once
 #include "vpt_mesh_kernel.hip.h"
 
 #ifndef VPT_K2_WAVES
-#define VPT_K2_WAVES 4
+#define VPT_K2_WAVES 4       // waves per SIMD (3: -6 %, 5: -30 %: 102 VGPRs spill the march state)
 #endif
 #ifndef VPT_K2_SHADE_AT
-#define VPT_K2_SHADE_AT 16   // lanes waiting for the shading block before the wave runs it
+#define VPT_K2_SHADE_AT 24   // lanes waiting for the shading block before the wave runs it (8: -11 %, 16: -4 %, 24: best, 32: -5 %)
 #endif
 #ifndef VPT_K2_WATCHDOG_TICKS
 #define VPT_K2_WATCHDOG_TICKS 30000000000ull   // 300 s: two orders of magnitude above the longest wave of any test workload
 #endif
+#ifndef VPT_K2_LIGHT_INLINE
+#define VPT_K2_LIGHT_INLINE 0   // 1: an SDF light's pdf march runs to its end inside the shading block (measured: 145 against 179 Msamples/s); 0: as M_LIGHT trips of its own
+#endif
+#ifndef VPT_K2_LIGHT_AT
+#define VPT_K2_LIGHT_AT 8       // (1: 178, 8: 204, 16: 204 Msamples/s) lanes in M_LIGHT before the wave spends a round on light-march steps (while other lanes march the scene)
+#endif
 #ifndef VPT_K2_STEPS
-#define VPT_K2_STEPS 4       // march steps between two looks at the wave's state
+#define VPT_K2_STEPS 8       // march steps between two looks at the wave's state (2: -5 %, 4: -1.5 %, 8: best)
 #endif
 
-enum { M_NEW = 0, M_SCENE = 1, M_HIT = 2, M_MISS = 3, M_LIGHT = 4, M_LIGHTS = 5, M_DONE = 6, M_FETCH = 7 };
+// Diagnostic build (-DVPT_K2_STATS): where the lanes of a wave are, trip by trip (profiles/tools/k2_stats.py).  Never in the product build.
+#ifdef VPT_K2_STATS
+__device__ unsigned long long g_k2_stats[16];
+enum { KS_TRIPS, KS_SCENE_ROUNDS, KS_SCENE_LANES, KS_LIGHT_ROUNDS, KS_LIGHT_LANES, KS_SHADE_ROUNDS, KS_SHADE_LANES, KS_DONE_LANES,
+  KS_WAIT_LANES_AT_MARCH, KS_LIGHT_LANES_AT_SCENE, KS_SCENE_LANES_AT_SHADE, KS_COUNT };
+#define K2_STAT(k, v) stats[k] += (unsigned long long)(v)
+#else
+#define K2_STAT(k, v)
+#endif
+
+enum { M_NEW = 0, M_SCENE = 1, M_HIT = 2, M_MISS = 3, M_LIGHT = 4, M_LIGHTS = 5, M_DONE = 6 };
 
 // one step of spheretrace(scene, ray, maxiter) (yocto_pathtrace.cpp:289-307); returns the lane's next mode
-VPT_DEV int scene_march_step(const DScene& sc, f3 ro, f3 rd, int maxiter, float& t, int& it, int& hit_instance, int& hit_sdf) {
+VPT_DEV int scene_march_step(const DScene& sc, const sdf_recs& recs, f3 ro, f3 rd, int maxiter, float& t, int& it, int& hit_instance, int& hit_sdf) {
   if (!(it < maxiter && t < VPT_FLT_MAX)) return M_MISS;
-  sdf_hit res = eval_sdf_scene(sc, ro + rd * t, t);
+  f3      p   = ro + rd * t;
+  sdf_hit res = eval_sdf_scene(sc, recs, p, t);
   if (fabs_(res.result) < (VPT_FLT_EPS * t)) {
     hit_instance = res.instance, hit_sdf = res.sdf;
     return M_HIT;
+  }
+  // further from every SDF than the radius of the ball around all of them: if the ray also recedes from that ball (and,
+  // where the scene has unbounded SDFs - planes -, from each of those at a rate that outruns flt_eps * t), it misses
+  if (res.result > sc.sdf_bound_r && sc.sdf_bound_r > 0 &&
+      march_cannot_hit(mk3(sc.sdf_bound_cx, sc.sdf_bound_cy, sc.sdf_bound_cz), sc.sdf_bound_r, ro, p, rd)) {
+    bool recede = true;
+    if (sc.sdf_num_planes > 0) {   // flt_eps * t must stay below the planes' values (> r): t < 2e6 r as long as p is within 1e6 r of the ball
+      f3 pc = p - mk3(sc.sdf_bound_cx, sc.sdf_bound_cy, sc.sdf_bound_cz);
+      recede = dot(pc, pc) < 1e12f * sc.sdf_bound_r * sc.sdf_bound_r;
+    }
+    for (int idx = 0; sc.sdf_num_planes > 0 && idx < sc.num_sdfs; idx++) {
+      const float4* rec = recs.fn + 6 * idx;
+      if ((__float_as_int(rec[4].w) & 255) != VPT_SDF_PLANE) continue;
+      // plane value y(s) = y0 + s * ny along the ray, y0 >= the scene minimum > r > 0: with ny >= 1e-3 it outgrows flt_eps * (t + s)
+      float ny = transform_vector(unpack_frame(rec[0], rec[1], rec[2]), rd).y;
+      if (!(ny >= 1e-3f)) recede = false;
+    }
+    if (recede) return M_MISS;
   }
   t += res.result, it++;
   return M_SCENE;
 }
 // one step of spheretrace(scene, ray, sdf, maxiter) (:267-286) inside sample_lights_pdf (:382-394) for SDF light `sdf`:
 // on a hit adds the light's pdf term (normal at `position`, sic, :389) to `sum`; returns false when the march ended
-VPT_DEV bool light_march_step(const DScene& sc, const vpt_sdf& sdf, float area, f3 position, f3 direction, int maxiter, float& lt, int& lit, float& sum) {
+VPT_DEV bool light_march_step(const sdf_recs& recs, int sdf, float area, f3 position, f3 direction, int maxiter, float& lt, int& lit, float& sum) {
   if (!(lit < maxiter && lt < VPT_FLT_MAX)) return false;
-  float res = eval_sdf_function(sdf, transform_point(load_frame(sdf.frame), position + direction * lt));
+  f3    p   = position + direction * lt;
+  float res = sdf_fn_world(recs, sdf, p);
   if (fabs_(res) < (VPT_FLT_EPS * lt)) {
-    f3 lposition = position + direction * lt;
-    f3 lnormal   = eval_sdf_normal_function(sdf, position, lt);
-    sum += distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * area);
+    f3 lnormal = eval_sdf_normal_function(recs, sdf, position, lt);
+    sum += distance_squared(p, position) / (fabs_(dot(lnormal, direction)) * area);
     return false;
   }
+  float4 bound = recs.fn[6 * sdf + 5];
+  if (res > bound.w && bound.w > 0 && march_cannot_hit(xyz(bound), bound.w, position, p, direction)) return false;   // receding: a miss
   lt += res, lit++;
   return true;
 }
@@ -89,7 +131,7 @@ VPT_DEV float lights_pdf_k2(const DScene& sc, f3 position, f3 direction, int max
       const vpt_light& light = sc.lights[l];
       float lt = VPT_RAY_EPS;
       int   lit = 0;
-      while (light_march_step(sc, sc.sdfs[light.sdf], sc.light_cdf[light.cdf_offset + light.cdf_len - 1], position, direction, maxiter, lt, lit, sum)) {}
+      while (light_march_step(scene_sdf_recs(sc), light.sdf, sc.light_cdf[light.cdf_offset + light.cdf_len - 1], position, direction, maxiter, lt, lit, sum)) {}
     } else sum += inline_light_pdf(sc, l, kind, r6, r7, position, direction, stk);
   }
   return sum * ((float)1 / (float)sc.num_lights);
@@ -102,19 +144,40 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
   lane_stack stk;   // binary-node stack: only the pdf walk of an emissive mesh with a real BVH uses it
   stk.base = lds_stack + threadIdx.x;
   stk.cap  = stack_cap;
-  const unsigned long long wave_start = wall_clock64();
-  // ---- the lane's current pixel: state slot, pixel coordinates, running state (registers) -------------
-  int   slot = -1, px = 0, py = 0;
+  // the SDF records, copied once into LDS behind the stack (they are read at every march step, the same address by all lanes)
+  float4* lds_rec = (float4*)(lds_stack + (size_t)stack_cap * VPT_BLOCK);
+  const int nfn4 = 6 * sc.num_sdfs, ngrid4 = 7 * sc.num_vol_instances;
+  for (int i = threadIdx.x; i < nfn4; i += VPT_BLOCK) lds_rec[i] = sc.sdf_fn_rec[i];
+  for (int i = threadIdx.x; i < ngrid4; i += VPT_BLOCK) lds_rec[nfn4 + i] = sc.sdf_grid_rec[i];
+  __syncthreads();
+  sdf_recs recs;
+  recs.fn = lds_rec, recs.grid = lds_rec + nfn4;
+  __shared__ unsigned long long s_wave_start;   // the start stamp, parked in LDS (clock_ticks, vpt_math.hip.h)
+  if (threadIdx.x == 0) s_wave_start = clock_ticks(blockIdx.x);
+  __syncthreads();
+  const unsigned long long wave_start = s_wave_start;
+  int trips = 0;
+  const int wave = sched.order ? sched.order[blockIdx.x] : (int)blockIdx.x;
+
+  int slot = wave * VPT_BLOCK + threadIdx.x;
+  int px = 0, py = 0;
+  const bool owner = slot < pr.nslots && slot_to_pixel(pr, slot, px, py);   // padding lanes own no pixel: they stay M_DONE
+  if (__builtin_amdgcn_ballot_w64(owner) == 0) return;
+
+  // ---- pixel state: one coalesced read, kept in registers for the whole launch ----------------
   f4    acc = mk4(0, 0, 0, 0);
   rng_t rng = {0, 0};
-  unsigned age = 0;           // trips of the wave loop since the pixel was fetched: its cost for the next launch's order
-  bool  queue_empty = false;  // wave-uniform
+  if (owner) {
+    float4     acc_in = image[slot];
+    ulonglong2 r_in   = rngs[slot];
+    acc = mk4(acc_in.x, acc_in.y, acc_in.z, acc_in.w), rng.state = r_in.x, rng.inc = r_in.y;
+  }
   const vpt_camera& cam = sc.cameras[pr.camera];
   const int nb = pr.bounces, maxiter = pr.spheretrace_maxiter;
   const bool mis = !pr.noimplicit_mis;
 
   // ---- path state --------------------------------------------------------------------------------
-  int   mode = M_FETCH;
+  int   mode = owner ? M_NEW : M_DONE;
   f3    ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);          // current ray (tmin = 1e-4, tmax = flt_max)
   float t = VPT_RAY_EPS, lt = VPT_RAY_EPS;             // scene march / light march distance
   int   it = 0, lit = 0, hit_instance = -1, hit_sdf = -1;
@@ -126,36 +189,49 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
   float mis_pdf = 0, lp_sum = 0;
   int   lp_light = 0;
 
+#ifdef VPT_K2_STATS
+  unsigned long long stats[KS_COUNT] = {};
+#endif
+  bool gave_up = false;
   while (true) {
     // every wave reaches an exit: the state machine ends when all lanes are M_DONE; should a defect ever keep it from
     // getting there, the wave gives up after VPT_K2_WATCHDOG_TICKS of the 100 MHz clock and the launch reports it
-    if (wall_clock64() - wave_start > VPT_K2_WATCHDOG_TICKS) {
-      if (threadIdx.x == 0 && watchdog) atomicAdd(watchdog, 1u);
+    if (((++trips) & 255) == 0 && clock_ticks(trips) - wave_start > VPT_K2_WATCHDOG_TICKS) {
+      gave_up = true;
       break;
     }
     unsigned long long marching = __builtin_amdgcn_ballot_w64(mode == M_SCENE || mode == M_LIGHT);
-    unsigned long long waiting  = __builtin_amdgcn_ballot_w64(mode == M_NEW || mode == M_HIT || mode == M_MISS || mode == M_LIGHTS || mode == M_FETCH);
+    unsigned long long waiting  = __builtin_amdgcn_ballot_w64(mode == M_NEW || mode == M_HIT || mode == M_MISS || mode == M_LIGHTS);
     if ((marching | waiting) == 0) break;   // every lane M_DONE
-    age++;
+    K2_STAT(KS_TRIPS, 1);
+    K2_STAT(KS_DONE_LANES, 64 - __popcll(marching | waiting));
 
     if (marching != 0 && __popcll(waiting) < VPT_K2_SHADE_AT) {
       // ---- march steps ------------------------------------------------------------------------------
+      K2_STAT(KS_WAIT_LANES_AT_MARCH, __popcll(waiting));
       if (__builtin_amdgcn_ballot_w64(mode == M_SCENE) != 0) {
+        K2_STAT(KS_SCENE_ROUNDS, 1);
+        K2_STAT(KS_SCENE_LANES, __popcll(__builtin_amdgcn_ballot_w64(mode == M_SCENE)));
+        K2_STAT(KS_LIGHT_LANES_AT_SCENE, __popcll(__builtin_amdgcn_ballot_w64(mode == M_LIGHT)));
         for (int k = 0; k < VPT_K2_STEPS; k++)
-          if (mode == M_SCENE) mode = scene_march_step(sc, ro, rd, maxiter, t, it, hit_instance, hit_sdf);
+          if (mode == M_SCENE) mode = scene_march_step(sc, recs, ro, rd, maxiter, t, it, hit_instance, hit_sdf);
       }
       // SDF-light marches: cheap steps (one analytic SDF), several per trip; lanes of one light at a time so that the
       // light's record is wave-uniform (scalar loads)
       unsigned long long lm = __builtin_amdgcn_ballot_w64(mode == M_LIGHT);
+      if (__popcll(lm) < VPT_K2_LIGHT_AT && __builtin_amdgcn_ballot_w64(mode == M_SCENE) != 0) lm = 0;   // too few: let them wait for company
+      if (lm != 0) {
+        K2_STAT(KS_LIGHT_ROUNDS, 1);
+        K2_STAT(KS_LIGHT_LANES, __popcll(lm));
+      }
       while (lm != 0) {
         int  l    = __builtin_amdgcn_readlane(lp_light, __ffsll((long long)lm) - 1);   // the light of the first lane still to serve
         bool mine = mode == M_LIGHT && lp_light == l;
         if (mine) {
           const vpt_light& light = sc.lights[l];
-          const vpt_sdf&   sdf   = sc.sdfs[light.sdf];
           float area = sc.light_cdf[light.cdf_offset + light.cdf_len - 1];
           for (int k = 0; k < 4 * VPT_K2_STEPS; k++)
-            if (mode == M_LIGHT && !light_march_step(sc, sdf, area, ro, rd, maxiter, lt, lit, lp_sum)) mode = M_LIGHTS, lp_light++;
+            if (mode == M_LIGHT && !light_march_step(recs, light.sdf, area, ro, rd, maxiter, lt, lit, lp_sum)) mode = M_LIGHTS, lp_light++;
         }
         lm &= ~__builtin_amdgcn_ballot_w64(mine);
       }
@@ -163,14 +239,17 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
     }
 
     // ---- shading block: the lanes that wait for it ---------------------------------------------------
+    K2_STAT(KS_SHADE_ROUNDS, 1);
+    K2_STAT(KS_SHADE_LANES, __popcll(waiting));
+    K2_STAT(KS_SCENE_LANES_AT_SHADE, __popcll(marching));
     bool finish = false, next_vertex = false;   // next_vertex: a path vertex was completed, the new ray is in (ro, rd)
     if (mode == M_MISS) {   // cpp:444-447 / 545
       if constexpr (SH == K_IMPLICIT) radiance = radiance + weight * eval_environment(sc, rd);
       finish = true;
     } else if (mode == M_HIT) {
       f3 position = ro + rd * t;
-      f3 normal   = hit_instance != VPT_INVALID ? eval_sdf_normal_grid(sc, sc.vol_instances[hit_instance], position, t)
-                                                : eval_sdf_normal_function(sc.sdfs[hit_sdf], position, t);
+      f3 normal   = hit_instance != VPT_INVALID ? eval_sdf_normal_grid(sc, recs, hit_instance, position, t)
+                                                : eval_sdf_normal_function(recs, hit_sdf, position, t);
       if constexpr (SH == K_IMPLICIT_NORMAL) {   // cpp:538-562
         radiance = normal * 0.5f + 0.5f;
         alpha    = 1;
@@ -226,8 +305,16 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
         while (lp_light < sc.num_lights) {
           float4 r6 = sc.light_rec[8 * lp_light + 6], r7 = sc.light_rec[8 * lp_light + 7];
           int    kind = __float_as_int(r7.w) & 255;
-          if (kind == VPT_LIGHT_SDF) {   // needs a march: hand over
-            lt = VPT_RAY_EPS, lit = 0, mode = M_LIGHT;
+          if (kind == VPT_LIGHT_SDF) {
+            lt = VPT_RAY_EPS, lit = 0;
+            if (VPT_K2_LIGHT_INLINE) {   // experiment: see the macro
+              const vpt_light& light = sc.lights[lp_light];
+              float area = sc.light_cdf[light.cdf_offset + light.cdf_len - 1];
+              while (light_march_step(recs, light.sdf, area, ro, rd, maxiter, lt, lit, lp_sum)) {}
+              lp_light++;
+              continue;
+            }
+            mode = M_LIGHT;   // needs a march: hand over
             break;
           }
           lp_sum += inline_light_pdf(sc, lp_light, kind, r6, r7, ro, rd, stk);
@@ -252,44 +339,10 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
       acc = acc + rad;
       sample++;
       mode = M_NEW;
-      if (sample == pr.nsamples) {   // the pixel is done: its state goes back to HBM, the lane takes another pixel
-        image[slot] = make_float4(acc.x, acc.y, acc.z, acc.w);
-        hits[slot] += pr.nsamples;
-        ulonglong2 r_out;
-        r_out.x = rng.state, r_out.y = rng.inc;
-        rngs[slot] = r_out;
-        if (sched.cost) sched.cost[slot] = age;
-        mode = M_FETCH;
-      }
-    }
-    // ---- pixel queue: one atomic per batch of fetching lanes; slots that hold no pixel (padding of the last tiles) are skipped
-    while (true) {
-      unsigned long long need = __builtin_amdgcn_ballot_w64(mode == M_FETCH);
-      if (need == 0) break;
-      if (queue_empty) {
-        if (mode == M_FETCH) mode = M_DONE;
-        break;
-      }
-      int n = __popcll(need), base = 0;
-      if ((int)threadIdx.x == __ffsll((long long)need) - 1) base = atomicAdd(sched.next, n);
-      base = __builtin_amdgcn_readlane(base, __ffsll((long long)need) - 1);
-      queue_empty = base + n >= sched.total;
-      if (mode == M_FETCH) {
-        int idx = base + __popcll(need & ((1ull << threadIdx.x) - 1));
-        if (idx >= sched.total) mode = M_DONE;
-        else {
-          slot = sched.order ? sched.order[idx] : idx;
-          if (slot_to_pixel(pr, slot, px, py)) {
-            float4     acc_in = image[slot];
-            ulonglong2 r_in   = rngs[slot];
-            acc = mk4(acc_in.x, acc_in.y, acc_in.z, acc_in.w), rng.state = r_in.x, rng.inc = r_in.y;
-            sample = 0, age = 0, mode = M_NEW;
-          }
-        }
-      }
     }
     if (mode == M_NEW) {
-      {
+      if (sample == pr.nsamples) mode = M_DONE;
+      else {
         float u, v;
         if (pr.preview) {
           u = (px + 0.5f) / pr.width, v = (py + 0.5f) / pr.height;
@@ -310,4 +363,20 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
     }
   }
 
+  if (gave_up && threadIdx.x == 0 && watchdog) atomicAdd(watchdog, 1u);
+  if (owner) {
+    image[slot] = make_float4(acc.x, acc.y, acc.z, acc.w);
+    hits[slot] += pr.nsamples;
+    ulonglong2 r_out;
+    r_out.x = rng.state, r_out.y = rng.inc;
+    rngs[slot] = r_out;
+  }
+#ifdef VPT_K2_STATS
+  if (threadIdx.x == 0)
+    for (int k = 0; k < KS_COUNT; k++) atomicAdd(&g_k2_stats[k], stats[k]);
+#endif
+  if (sched.cost && threadIdx.x == 0) {
+    unsigned long long dt = clock_ticks(__float_as_int(acc.x)) - wave_start;   // after the last sample was accumulated
+    sched.cost[wave] = dt < 0xffffffffull ? (unsigned)dt : 0xffffffffu;
+  }
 }

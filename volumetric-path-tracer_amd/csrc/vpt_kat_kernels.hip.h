@@ -108,12 +108,12 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_kat_kernel(
     case VPT_KAT_LIGHTS_PDF: o[0] = kat_lights_pdf_k1(sc, ld3(a), ld3(a + 3), iparam, stk4); break;
     case VPT_KAT_LIGHTS_PDF_K2: o[0] = lights_pdf_k2(sc, ld3(a), ld3(a + 3), iparam, stk2); break;
     case VPT_KAT_SDF_SCENE: {
-      sdf_hit r = eval_sdf_scene(sc, ld3(a), a[3]);
+      sdf_hit r = eval_sdf_scene(sc, scene_sdf_recs(sc), ld3(a), a[3]);
       o[0] = r.result, o[1] = (float)r.instance, o[2] = (float)r.sdf;
     } break;
     case VPT_KAT_SDF_NORMAL: {
       int idx = (int)a[1];
-      f3  nrm = (int)a[0] == 0 ? eval_sdf_normal_grid(sc, sc.vol_instances[idx], ld3(a + 2), a[5]) : eval_sdf_normal_function(sc.sdfs[idx], ld3(a + 2), a[5]);
+      f3  nrm = (int)a[0] == 0 ? eval_sdf_normal_grid(sc, scene_sdf_recs(sc), idx, ld3(a + 2), a[5]) : eval_sdf_normal_function(scene_sdf_recs(sc), idx, ld3(a + 2), a[5]);
       kat_put3(o, nrm);
     } break;
     case VPT_KAT_SPHERETRACE: {
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_kat_kernel(
       if (sdf < 0) {   // the whole-scene form as K2 runs it: scene_march_step until the march ends
         float t = VPT_RAY_EPS;
         int   it = 0, inst = -1, fn = -1, mode;
-        do mode = scene_march_step(sc, ld3(a), ld3(a + 3), iparam, t, it, inst, fn);
+        do mode = scene_march_step(sc, scene_sdf_recs(sc), ld3(a), ld3(a + 3), iparam, t, it, inst, fn);
         while (mode == M_SCENE);
         o[0] = mode == M_HIT ? 1.0f : 0.0f, o[1] = mode == M_HIT ? t : VPT_FLT_MAX, o[2] = (float)inst, o[3] = (float)fn;
       } else {         // the single-SDF form (K1's SDF-light pdf; K2's is covered by VPT_KAT_LIGHTS_PDF_K2)
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_kat_kernel(
       }
     } break;
     case VPT_KAT_VOLUME: o[0] = eval_volume(sc, sc.volumes[(int)a[0]], ld3(a + 1)); break;
-    case VPT_KAT_SDF_FUNCTION: o[0] = eval_sdf_function(sc.sdfs[(int)a[0]], ld3(a + 1)); break;
+    case VPT_KAT_SDF_FUNCTION: o[0] = sdf_fn_local(sc.sdf_fn_rec + 6 * (int)a[0], ld3(a + 1)); break;
     default: break;
   }
 }

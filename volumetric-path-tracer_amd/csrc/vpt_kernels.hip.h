@@ -38,10 +38,8 @@ VPT_DEV bool survive(f3& weight, int bounce, rng_t& rng) {
 // waves longest first (order[] = wave indices by descending cost: LPT list scheduling).  Results do not depend
 // on the order (pixels are independent), only the makespan does.
 struct sched_cfg {
-  const int* order;   // K1: blockIdx.x -> wave index; K2: queue position -> state slot; or null: identity
-  unsigned*  cost;    // K1: per wave, duration of this launch in 100 MHz ticks; K2: per slot, trips its pixel took; or null
-  int*       next;    // K2: head of the pixel queue (zeroed by the host before the launch)
-  int        total;   // K2: entries in the queue (= state slots of this rank)
+  const int* order;   // blockIdx.x -> wave index, or null: identity
+  unsigned*  cost;    // per wave: duration of this launch in 100 MHz ticks, or null
 };
 // ---- state layout conversion and output resolve ---------------------------------------------
 // row-major host-order arrays <-> this rank's tile-major slots (vpt_state_upload / _download)

@@ -117,6 +117,20 @@ VPT_DEV frame load_frame(const vpt_frame& v) {
 }
 VPT_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
+// The 100 MHz wall clock (s_memrealtime) WITHOUT telling the compiler that memory changed.  wall_clock64(),
+// __builtin_readcyclecounter() and a volatile asm all count as a write to unknown memory, and after one such call the
+// compiler turns reads of wave-uniform tables from scalar loads (s_load, SGPR results) into per-lane vector loads
+// (checked on a six-line kernel).  This asm is pure in the compiler's eyes; `dep` is any value that must be computed
+// before the read (it keeps two reads from being merged and this one from moving above that value), and a reader that
+// must stay at the kernel's start parks the result in LDS at once (a store the read cannot sink below).  Measured
+// effect on the shipped kernels: none (K1 622 = 622, K2 252 = 255 Msamples/s) - what sits on K2's step was the
+// record reads, now staged in LDS; kept because it costs nothing and removes a trap.
+VPT_DEV unsigned long long clock_ticks(int dep) {
+  unsigned long long t;
+  asm("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(dep));
+  return t;
+}
+
 // PCG32, yocto_sampling.h:184-216 — bit-exact integer arithmetic
 struct rng_t { unsigned long long state, inc; };
 VPT_DEV unsigned int advance_rng(rng_t& rng) {

@@ -413,7 +413,7 @@ VPT_DEV float other_light_pdf(const DScene& sc, int light_id, int kind, float4 r
     st_hit h = spheretrace_one(sc, position, direction, light.sdf, maxiter);
     if (!h.hit) return 0;
     f3 lposition = position + direction * h.dist;
-    f3 lnormal   = eval_sdf_normal_function(sc.sdfs[h.sdf], position, h.dist);
+    f3 lnormal   = eval_sdf_normal_function(scene_sdf_recs(sc), h.sdf, position, h.dist);
     return distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * cdf[light.cdf_len - 1]);
   }
   if (kind == VPT_LIGHT_ENV_TEX) {
@@ -498,7 +498,8 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
     ulonglong2* __restrict__ rngs, const stack_cfg& stack, const sched_cfg& sched) {
   extern __shared__ int lds_stack[];
   const lane_stack2<SPILL> stk = make_lane_stack<SPILL>(lds_stack, stack);
-  const unsigned long long wave_start = wall_clock64();
+  __shared__ unsigned long long s_wave_start;   // the start stamp, parked in LDS (clock_ticks, vpt_math.hip.h)
+  if (threadIdx.x == 0) s_wave_start = clock_ticks(blockIdx.x);
   const int wave = sched.order ? sched.order[blockIdx.x] : (int)blockIdx.x;
 #ifdef VPT_COUNTERS
   if (threadIdx.x < 16) s_vpt_time[threadIdx.x] = 0;
@@ -787,7 +788,8 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
   r_out.x = rng.state, r_out.y = rng.inc;
   rngs[slot] = r_out;
   if (sched.cost && threadIdx.x == 0) {   // lane 0 (the tile's corner pixel) exists whenever the wave owns a pixel
-    unsigned long long dt = wall_clock64() - wave_start;
+    const unsigned long long wave_start = s_wave_start;
+    unsigned long long dt = clock_ticks(__float_as_int(acc.x)) - wave_start;   // after the last sample was accumulated
     sched.cost[wave] = dt < 0xffffffffull ? (unsigned)dt : 0xffffffffu;
 #ifdef VPT_WAVE_TIMES
     if (wave < 65536) g_vpt_wave_times[2 * wave] = wave_start, g_vpt_wave_times[2 * wave + 1] = wave_start + dt;

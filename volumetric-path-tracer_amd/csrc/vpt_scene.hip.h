@@ -891,16 +891,40 @@ VPT_DEV float sd_capped_cone(f3 p, float h, float r1, float r2) {
   float s = (cb.x < 0.0f && ca.y < 0.0f) ? -1.0f : 1.0f;
   return s * sqrtf(fmin_(dot(ca, ca), dot(cb, cb)));
 }
-VPT_DEV float eval_sdf_function(const vpt_sdf& sdf, f3 p) {
-  switch (sdf.type) {
-    case VPT_SDF_BBOX: return sd_bbox(p, mk3(sdf.p[1], sdf.p[2], sdf.p[3]), sdf.p[0]);
-    case VPT_SDF_BOX: return sd_box(p - (ld3(sdf.whd) * 0.5f), ld3(sdf.whd) * 0.5f);
-    case VPT_SDF_CAPPED_CONE: return sd_capped_cone(p, sdf.p[0], sdf.p[1], sdf.p[2]);
+// SDF records (vpt_device.h, DScene::sdf_fn_rec / sdf_grid_rec): per analytic SDF / per voxel-grid instance, everything
+// an evaluation needs behind ONE wave-uniform index, with the constants the reference recomputes at every evaluation
+// (half extents, grid box size) folded on the host by the same float operations (vpt_capi.hip).
+//   fn   [0..2] forward frame (packed)  [3] p[0..3]  [4] {whd * 0.5, type | translation << 8}  [5] {world centre, radius} (radius < 0: unbounded)
+//   grid [0..2] forward frame (packed)  [3] {box size, scalef}  [4] {box size * 0.5, translation}  [5] {W, H, D, res}  [6] {voxel offset lo, hi}
+// transform_point(frame, p): for a frame whose rotation part is exactly the identity the products 1 * p.x + 0 * p.y + 0 * p.z
+// equal p.x (a zero term never changes a finite sum; only the sign of an exact zero can differ, which every sd_* below
+// discards: they take abs / squares / compare with 0), so such frames take three additions.
+// Where the records are read from: the scene's tables in HBM (DScene::sdf_fn_rec / sdf_grid_rec), or a copy a kernel made
+// in its LDS (K2: the records are wave-uniform and read six times per march step; from HBM each read is a vector load
+// with its full latency on the critical path of the step, from LDS a broadcast ds_read).
+struct sdf_recs { const float4 *fn, *grid; };
+VPT_DEV sdf_recs scene_sdf_recs(const DScene& sc) { sdf_recs r = {sc.sdf_fn_rec, sc.sdf_grid_rec}; return r; }
+VPT_DEV f3 sdf_to_local(const float4* rec, bool translation, f3 pw) {
+  float4 r2 = rec[2];
+  if (translation) return mk3(pw.x + r2.y, pw.y + r2.z, pw.z + r2.w);
+  return transform_point(unpack_frame(rec[0], rec[1], r2), pw);
+}
+// sdf_data::f of the reference (the lambdas of yocto_sceneio.cpp:3684-3730) at a point of the SDF's local frame
+VPT_DEV float sdf_fn_local(const float4* rec, f3 p) {
+  float4 q = rec[3], h = rec[4];
+  switch (__float_as_int(h.w) & 255) {
+    case VPT_SDF_BBOX: return sd_bbox(p, mk3(q.y, q.z, q.w), q.x);
+    case VPT_SDF_BOX: return sd_box(p - xyz(h), xyz(h));   // sd_box(p - whd * 0.5, whd * 0.5)
+    case VPT_SDF_CAPPED_CONE: return sd_capped_cone(p, q.x, q.y, q.z);
     case VPT_SDF_PLANE: return p.y;
-    case VPT_SDF_SPHERE: return length(p) - sdf.p[0];
-    case VPT_SDF_TORUS: return length(mk2(length(mk2(p.x, p.z)) - sdf.p[0], p.y)) - sdf.p[1];
+    case VPT_SDF_SPHERE: return length(p) - q.x;
+    case VPT_SDF_TORUS: return length(mk2(length(mk2(p.x, p.z)) - q.x, p.y)) - q.y;
     default: return VPT_FLT_MAX;
   }
+}
+VPT_DEV float sdf_fn_world(const sdf_recs& recs, int idx, f3 pw) {   // sdf.f(transform_point(sdf.frame, p)), yocto_sdfs.cpp:21
+  const float4* rec = recs.fn + 6 * idx;
+  return sdf_fn_local(rec, sdf_to_local(rec, (__float_as_int(rec[4].w) >> 8) & 1, pw));
 }
 // eval_volume: 8-tap trilinear in the reference's term order, yocto_sdfs.cpp:92-127
 VPT_DEV float eval_volume(const DScene& sc, const vpt_volume& vol, f3 uvw) {
@@ -922,65 +946,81 @@ VPT_DEV float eval_volume(const DScene& sc, const vpt_volume& vol, f3 uvw) {
          v001 * (1 - u) * (1 - v) * w + v011 * (1 - u) * v * w + v101 * u * (1 - v) * w + v110 * u * v * (1 - w) +
          v111 * u * v * w;
 }
-VPT_DEV float eval_sdf_grid(const DScene& sc, const vpt_volume_instance& inst, f3 p, float t) {   // yocto_sdfs.cpp:30-49
-  const vpt_volume& vol = sc.volumes[inst.volume];
-  f3 grid_res = mk3((float)vol.whd[0], (float)vol.whd[1], (float)vol.whd[2]);
-  f3 origin   = ld3(inst.frame.o);
-  f3 bbox_max  = origin + (vol.res * grid_res) * inst.scalef;
-  f3 bbox_size = (bbox_max - origin);
-  float bbox_dist = sd_box(p - (bbox_size * 0.5f), (bbox_size * 0.5f));
+// eval_sdf(volume, instance, p_local, t) behind the instance's transform, yocto_sdfs.cpp:13 + 30-49
+VPT_DEV float sdf_grid_world(const DScene& sc, const sdf_recs& recs, int idx, f3 pw, float t) {
+  const float4* rec = recs.grid + 7 * idx;
+  float4 sz = rec[3], hf = rec[4];
+  f3     p  = sdf_to_local(rec, __float_as_int(hf.w) & 1, pw);
+  float  bbox_dist = sd_box(p - xyz(hf), xyz(hf));
   if (bbox_dist < VPT_FLT_EPS * t) {
-    f3 uvw = p * 2.f / (bbox_size)-1;
-    return eval_volume(sc, vol, uvw) * inst.scalef;
+    float4 g = rec[5], o = rec[6];
+    vpt_volume vol;
+    vol.whd[0] = __float_as_int(g.x), vol.whd[1] = __float_as_int(g.y), vol.whd[2] = __float_as_int(g.z), vol.res = g.w;
+    vol.offset = (long long)(unsigned)__float_as_int(o.x) | ((long long)__float_as_int(o.y) << 32);
+    f3 uvw = p * 2.f / xyz(sz) - 1;
+    return eval_volume(sc, vol, uvw) * sz.w;
   }
   return bbox_dist;
 }
 struct sdf_hit { float result; int instance, sdf; };
-VPT_DEV sdf_hit eval_sdf_scene(const DScene& sc, f3 p, float t) {   // yocto_sdfs.cpp:7-26 (first minimum wins ties)
+VPT_DEV sdf_hit eval_sdf_scene(const DScene& sc, const sdf_recs& recs, f3 p, float t) {   // yocto_sdfs.cpp:7-26 (first minimum wins ties)
   sdf_hit res = {VPT_FLT_MAX, -1, -1};
   for (int idx = 0; idx < sc.num_vol_instances; idx++) {
-    const vpt_volume_instance& inst = sc.vol_instances[idx];
-    float d = eval_sdf_grid(sc, inst, transform_point(load_frame(inst.frame), p), t);
+    float d = sdf_grid_world(sc, recs, idx, p, t);
     if (d < res.result) res.result = d, res.instance = idx, res.sdf = -1;
   }
   for (int idx = 0; idx < sc.num_sdfs; idx++) {
-    const vpt_sdf& sdf = sc.sdfs[idx];
-    float d = eval_sdf_function(sdf, transform_point(load_frame(sdf.frame), p));
+    float d = sdf_fn_world(recs, idx, p);
     if (d < res.result) res.result = d, res.instance = -1, res.sdf = idx;
   }
   return res;
 }
 // tetrahedral 4-tap normals, yocto_sdfs.cpp:67-89
-VPT_DEV f3 eval_sdf_normal_function(const vpt_sdf& sdf, f3 p, float t) {
+VPT_DEV f3 eval_sdf_normal_function(const sdf_recs& recs, int idx, f3 p, float t) {
   float h = VPT_FLT_EPS * t;
-  frame f = load_frame(sdf.frame);
-  float d1 = eval_sdf_function(sdf, transform_point(f, p + mk3(1, -1, -1) * h));
-  float d2 = eval_sdf_function(sdf, transform_point(f, p + mk3(-1, -1, 1) * h));
-  float d3 = eval_sdf_function(sdf, transform_point(f, p + mk3(-1, 1, -1) * h));
-  float d4 = eval_sdf_function(sdf, transform_point(f, p + mk3(1, 1, 1) * h));
+  float d1 = sdf_fn_world(recs, idx, p + mk3(1, -1, -1) * h);
+  float d2 = sdf_fn_world(recs, idx, p + mk3(-1, -1, 1) * h);
+  float d3 = sdf_fn_world(recs, idx, p + mk3(-1, 1, -1) * h);
+  float d4 = sdf_fn_world(recs, idx, p + mk3(1, 1, 1) * h);
   return normalize(mk3(1, -1, -1) * d1 + mk3(-1, -1, 1) * d2 + mk3(-1, 1, -1) * d3 + mk3(1, 1, 1) * d4);
 }
-VPT_DEV f3 eval_sdf_normal_grid(const DScene& sc, const vpt_volume_instance& inst, f3 p, float t) {
+VPT_DEV f3 eval_sdf_normal_grid(const DScene& sc, const sdf_recs& recs, int idx, f3 p, float t) {
   float h = VPT_FLT_EPS * t;
-  frame f = load_frame(inst.frame);
-  float d1 = eval_sdf_grid(sc, inst, transform_point(f, p + mk3(1, -1, -1) * h), t);
-  float d2 = eval_sdf_grid(sc, inst, transform_point(f, p + mk3(-1, -1, 1) * h), t);
-  float d3 = eval_sdf_grid(sc, inst, transform_point(f, p + mk3(-1, 1, -1) * h), t);
-  float d4 = eval_sdf_grid(sc, inst, transform_point(f, p + mk3(1, 1, 1) * h), t);
+  float d1 = sdf_grid_world(sc, recs, idx, p + mk3(1, -1, -1) * h, t);
+  float d2 = sdf_grid_world(sc, recs, idx, p + mk3(-1, -1, 1) * h, t);
+  float d3 = sdf_grid_world(sc, recs, idx, p + mk3(-1, 1, -1) * h, t);
+  float d4 = sdf_grid_world(sc, recs, idx, p + mk3(1, 1, 1) * h, t);
   return normalize(mk3(1, -1, -1) * d1 + mk3(-1, -1, 1) * d2 + mk3(-1, 1, -1) * d3 + mk3(1, 1, 1) * d4);
+}
+
+// A march can be cut short without changing its outcome once it can only end in a miss.  For a BOUNDED SDF (or set of
+// SDFs) inside the ball (c, r): if the point p = o + t d lies outside the ball of radius 2 r, moves away from c
+// (d . (p - c) >= 0) and |o - c| < 1e6 r, no later step of the reference's loop can report a hit:
+//   * every later point p' has |p' - c| >= |p - c| > 2 r, so its true distance to the content is >= |p' - c| - r > r;
+//   * the sd_* functions are exact distances outside their shapes, evaluated with a relative error of a few ulp, so the
+//     value the reference computes is >= 0.999 (|p' - c| - r) > 0;
+//   * a hit needs |value| < flt_eps * t' with t' = |p' - o| <= |p' - c| + |c - o|; but 0.999 (x - r) >= 1.2e-7 (x + 1e6 r)
+//     for every x >= 2 r (the left side is 0.999 r at x = 2 r and grows faster), so the test fails at every step;
+//   * hence the loop ends by i == maxiter or by t overflowing: a miss either way — what is returned here at once.
+// (The reference itself needs ~130 doublings of t to get an escaping ray past flt_max.)
+VPT_DEV bool march_cannot_hit(f3 c, float r, f3 o, f3 p, f3 d) {
+  f3 pc = p - c, oc = o - c;
+  return dot(pc, pc) > 4 * r * r && dot(pc, d) >= 0 && dot(oc, oc) < 1e12f * r * r;
 }
 struct st_hit { bool hit; float dist; int instance, sdf; };
 VPT_DEV st_hit spheretrace_one(const DScene& sc, f3 ro, f3 rd, int sdf_handle, int maxiter) {   // cpp:267-286
   st_hit r = {false, VPT_FLT_MAX, -1, -1};
   float  t = VPT_RAY_EPS;
-  const vpt_sdf& sdf = sc.sdfs[sdf_handle];
-  frame  f   = load_frame(sdf.frame);
+  const sdf_recs recs = scene_sdf_recs(sc);
+  float4 bound = recs.fn[6 * sdf_handle + 5];
   for (int i = 0; i < maxiter && t < VPT_FLT_MAX; ++i) {
-    float res = eval_sdf_function(sdf, transform_point(f, ro + rd * t));
+    f3    p   = ro + rd * t;
+    float res = sdf_fn_world(recs, sdf_handle, p);
     if (fabs_(res) < (VPT_FLT_EPS * t)) {
       r.hit = true, r.dist = t, r.sdf = sdf_handle;
       return r;
     }
+    if (res > bound.w && bound.w > 0 && march_cannot_hit(xyz(bound), bound.w, ro, p, rd)) return r;   // receding from a bounded SDF: a miss
     t += res;
   }
   return r;

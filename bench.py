@@ -8,11 +8,14 @@ A *step* is one launch of the hot path over the whole frame: `--spp` (256) sampl
 pixel, with the pixel state (radiance sums, hit counts, PCG32 streams) already resident in HBM in
 the tile-major layout of include/vpt.h.  Launches start their waves longest first, using the per-wave
 durations the previous launch on the same layout recorded; the very first launch of a
-process measures them with a one-sample pilot, which therefore falls into the warm-up.  With N GPUs the frame is cut into 8x8-pixel tiles dealt
-round-robin to the ranks (tile t -> rank t % N); each step ends with an RCCL all_gather of the
-ranks' tile buffers over xGMI and a resolve kernel on every rank.  Scaling is
-reported as WEAK: the per-GPU pixel count is fixed, i.e. the frame is 1280*sqrt(N) wide (N=8 ->
-3620x1508, the size class of BASELINE config[4]); `--strong` keeps the 1280-wide frame instead.
+process measures them with a short pilot, which therefore falls into the warm-up — the line's `cold` record
+times exactly that first call on a fresh scene handle (N = 1).
+
+N GPUs: the frame is FIXED (1280 wide unless --resolution says otherwise: BASELINE config[4] is --resolution 3840)
+and cut into 8x8-pixel tiles dealt round-robin to the ranks (tile t -> rank t % N); each step ends with an RCCL
+all_gather of the ranks' tile buffers over xGMI and a resolve kernel on every rank.  `scaling` is
+therefore "strong", and after the timed region rank 0 renders the same frame alone (the other ranks wait) so that the
+line carries `speedup_vs_1gpu` measured in the same job.  `--weak` instead grows the frame with N (width x sqrt(N)).
 
 The JSON line carries, besides the driver's contract:
   roofline      algorithmic bytes per launch (SURVEY §8(d) formula, event counts measured by the CPU
@@ -61,10 +64,12 @@ def main():
     ap.add_argument("--bounces", type=int, default=64)
     ap.add_argument("--shader", default="volpathtrace")
     ap.add_argument("--scene", default=SCENE)
-    ap.add_argument("--strong", action="store_true", help="fixed 1280-wide frame for every N")
+    ap.add_argument("--weak", action="store_true", help="grow the frame with N (width x sqrt(N)) instead of the fixed frame")
+    ap.add_argument("--strong", action="store_true", help="(default, kept for older command lines) fixed frame for every N")
     ap.add_argument("--cpu-sample", default="640x96", help="cpu baseline sample: <resolution>x<spp>; '0' disables")
     ap.add_argument("--tile", type=int, default=8)
     ap.add_argument("--balance", action="store_true", help="add per-wave duration statistics of the last launch to the line")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold first-call measurement (N = 1)")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,7 +92,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    resolution = args.resolution if args.strong else int(round(args.resolution * (world ** 0.5)))
+    resolution = int(round(args.resolution * (world ** 0.5))) if args.weak else args.resolution
     scene = vpt.HostScene(args.scene)
     # params.samples bounds the progressive render; keep it out of reach (and != 1: preview branch)
     params = vpt.PathtraceParams(resolution=resolution, samples=1 << 30, shader=args.shader, bounces=args.bounces)
@@ -141,6 +146,43 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- N > 1: the same frame on rank 0 alone, for the speed-up (the other ranks wait at the barrier) ----------
+    single = None
+    if world > 1 and not args.weak:
+        if rank == 0:
+            lay1 = vpt.VptLayout(width, height, args.tile, args.tile, 0, 1)
+            n1 = vpt.layout_slots(lay1)
+            i1 = torch.zeros((n1, 4), dtype=torch.float32, device=device)
+            h1 = torch.zeros((n1,), dtype=torch.int32, device=device)
+            r1 = torch.zeros((n1, 2), dtype=torch.int64, device=device)
+            vpt.state_upload(lay1, state, i1.data_ptr(), h1.data_ptr(), r1.data_ptr())
+            solo_steps = max(1, min(args.steps, 2))
+            for k in range(1 + solo_steps):   # one warm-up launch (pilot + order), then the timed ones
+                if k == 1:
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                dev.render_device(params, lay1, args.spp, i1.data_ptr(), h1.data_ptr(), r1.data_ptr(), stream)
+                vpt.resolve_device(lay1, i1.data_ptr(), (k + 1) * args.spp, frame.data_ptr(), stream)
+            torch.cuda.synchronize()
+            single = {"ms_per_step": round((time.perf_counter() - ts) / solo_steps * 1e3, 3), "steps": solo_steps}
+            del i1, h1, r1
+        dist.barrier()
+    # ---- N = 1: the first call on a fresh scene handle (no wave costs known: pilot launch + ordered launch) ---------
+    cold = None
+    if world == 1 and not args.no_cold:
+        dev2 = vpt.DeviceScene(scene, local_rank)
+        i2, h2, r2 = torch.zeros_like(d_image), torch.zeros_like(d_hits), torch.zeros_like(d_rng)
+        vpt.state_upload(layout, state, i2.data_ptr(), h2.data_ptr(), r2.data_ptr())
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        dev2.render_device(params, layout, args.spp, i2.data_ptr(), h2.data_ptr(), r2.data_ptr(), stream)
+        vpt.resolve_device(layout, i2.data_ptr(), args.spp, frame.data_ptr(), stream)
+        torch.cuda.synchronize()
+        cold_ms = (time.perf_counter() - tc) * 1e3
+        cold = {"ms": round(cold_ms, 3), "value": round(width * height * args.spp / cold_ms * 1e-3, 3), "unit": "Msamples/s",
+                "what": "first call on a fresh scene handle: no wave costs known yet, so a pilot launch (spp/64 samples) measures "
+                        "them and the rest runs in its order; `value` above is the steady state (order from the previous launch)"}
+        del dev2, i2, h2, r2
     scene_name = os.path.basename(os.path.dirname(os.path.abspath(args.scene)))
     data_desc = ("reference scene tests/03_volume (real assets), deterministic PCG32 seeds" if args.scene == SCENE else
                  f"{scene_name}: substitute assets (tests/golden/make_scenes.py), deterministic PCG32 seeds")
@@ -204,15 +246,20 @@ def main():
         line = {
             "metric": "Msamples/sec", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": "f32", "data": data_desc,
-            "config": {"workload": f"{scene_name} {args.shader} bounces={args.bounces} {width}x{height}x{args.spp}spp per step",
+            "config": {"workload": f"{scene_name} {args.shader} bounces={args.bounces} {width}x{height}x{args.spp}spp per step" + ("" if world == 1 else (", frame grows with N" if args.weak else ", fixed frame")),
                        "tile": f"{args.tile}x{args.tile}", "parallelism": f"tiles%{world}" if world > 1 else "1gpu",
                        "samples_per_step": samples_per_step},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         if balance:
             line["balance"] = balance
+        if cold:
+            line["cold"] = cold
+        if single:
+            line["single_gpu"] = single
+            line["speedup_vs_1gpu"] = round(single["ms_per_step"] / (elapsed / args.steps * 1e3), 3)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

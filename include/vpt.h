@@ -251,6 +251,23 @@ void vpt_scene_destroy(vpt_scene* scene);
 int vpt_render(vpt_scene* scene, const vpt_params* params, int nsamples, int width, int height,
                float* image_rgba, int32_t* hits, uint64_t* rng, int* samples_io);
 
+/* ---- the same over several GPUs of this process ("multi-GPU fan-out is internal", §8(e)) ----------
+ * One host thread per GPU; the frame's 8x8-pixel tiles are dealt round-robin (tile t -> devices[t % ndev]); every
+ * device holds the whole scene and the state of its own tiles, so rendering needs no communication and the result is
+ * bit-identical to vpt_render's (pixels own their RNG streams).  vpt_multi_get_render assembles the frame on
+ * devices[0]: the float4 tile buffers travel there over xGMI by grouped RCCL send / receive (RCCL is loaded on first
+ * use; ndev == 1 never touches it) and are resolved by the kernel of vpt_resolve_device. */
+typedef struct vpt_multi vpt_multi;
+int  vpt_multi_create(const vpt_scene_desc* desc, const int* devices, int ndev, vpt_multi** out);
+void vpt_multi_destroy(vpt_multi* m);
+int  vpt_multi_device_count(const vpt_multi* m);
+/* pathtrace_samples over all GPUs of `m`: the contract of vpt_render */
+int  vpt_multi_render(vpt_multi* m, const vpt_params* params, int nsamples, int width, int height,
+                      float* image_rgba, int32_t* hits, uint64_t* rng, int* samples_io);
+/* get_render (yocto_pathtrace.cpp:1105-1116) of the state the last vpt_multi_render left on the devices: row-major
+ * float4 image * (1 / samples) into the caller's host buffer, gathered and resolved on devices[0] */
+int  vpt_multi_get_render(vpt_multi* m, float* image_rgba);
+
 /* ---- device-resident state (bench / multi-GPU; buffers owned by the caller, e.g. torch) */
 /* number of state slots a rank needs for `layout` (multiple of tile_w*tile_h) */
 int64_t vpt_layout_slots(const vpt_layout* layout);

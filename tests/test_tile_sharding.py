@@ -2,8 +2,8 @@
 pixel set into disjoint per-rank slot lists, every rank renders only its own pixels, an
 all_gather of the tile buffers + the resolve map reassembles a frame that is BIT-IDENTICAL to the
 single-rank render (pixels own their RNG streams).  world_size 2 over gloo; the
-per-rank renderer here is the CPU oracle (this is a test of the sharding logic, not of the kernels —
-tests/test_gpu_parity.py repeats it on the device with two virtual ranks)."""
+per-rank renderer here is the CPU oracle restricted to the rank's pixel list (this is a test of the
+sharding logic, not of the kernels — tests/test_gpu_parity.py repeats it on the device with virtual ranks)."""
 import os
 import sys
 
@@ -47,11 +47,16 @@ def _worker(rank, world, port, out_path):
     lay = vpt.VptLayout(full.width, full.height, 8, 8, rank, world)
     idx = vpt.layout_pixel_index(lay)
     mine = idx[idx >= 0]
-    # this rank's pixels as a 1 x n strip: same streams, same camera coordinates via a gather of rows
-    # (the oracle renders whole frames, so render the frame and keep only the rank's pixels' results
-    #  from a state in which ONLY those pixels are allowed to advance)
+    # the rank renders ONLY its own pixels (vpt_oracle_render_pixels): every other pixel of its state must come back
+    # exactly as make_state left it - radiance and hit count zero, the RNG stream at its seed
     st = full.copy()
-    oracle_lib.oracle_render(scene, p, st, 3, nthreads=2)
+    oracle_lib.oracle_render(scene, p, st, 3, nthreads=2, pixels=mine)
+    foreign = np.ones(full.width * full.height, bool)
+    foreign[mine] = False
+    assert (st.hits.reshape(-1)[mine] == 3).all() and (st.hits.reshape(-1)[foreign] == 0).all(), "a rank touched a foreign pixel"
+    assert not st.image.reshape(-1, 4)[foreign].any()
+    assert np.array_equal(st.rngs.reshape(-1, 2)[foreign], full.rngs.reshape(-1, 2)[foreign])
+    assert (st.rngs.reshape(-1, 2)[mine, 0] != full.rngs.reshape(-1, 2)[mine, 0]).all()
     tiles = np.zeros((len(idx), 4), np.float32)
     tiles[idx >= 0] = st.image.reshape(-1, 4)[mine]
     gathered = [torch.zeros(len(idx), 4) for _ in range(world)]
@@ -67,6 +72,8 @@ def _worker(rank, world, port, out_path):
 
 
 def test_two_rank_gather_reassembles_the_single_rank_frame(vpt, scene03, oracle, tmp_path):
+    """each of the two gloo ranks renders only its tiles' pixels (the worker asserts that nothing else moved); the
+    gathered frame equals the single-rank render bit for bit"""
     out = str(tmp_path / "frame.npy")
     mp.spawn(_worker, args=(2, 29517, out), nprocs=2, join=True)
     p = vpt.PathtraceParams(resolution=96, samples=3, shader="volpathtrace", bounces=64)
@@ -74,3 +81,20 @@ def test_two_rank_gather_reassembles_the_single_rank_frame(vpt, scene03, oracle,
     oracle.oracle_render(scene03, p, st, 3)
     frame = np.load(out)
     assert np.array_equal(frame.view(np.uint32), st.image.view(np.uint32))
+
+
+def test_rendering_a_pixel_subset_leaves_the_rest_alone(vpt, scene03, oracle):
+    """the checker's own contract: vpt_oracle_render_pixels advances exactly the listed pixels, each as the whole-frame
+    render would"""
+    p = vpt.PathtraceParams(resolution=64, samples=2, shader="volpathtrace", bounces=64)
+    whole, part = scene03.make_state(p), scene03.make_state(p)
+    seed = part.copy()
+    oracle.oracle_render(scene03, p, whole, 2)
+    some = np.arange(0, whole.width * whole.height, 7, dtype=np.int32)
+    oracle.oracle_render(scene03, p, part, 2, pixels=some)
+    rest = np.ones(whole.width * whole.height, bool)
+    rest[some] = False
+    assert np.array_equal(part.image.reshape(-1, 4)[some].view(np.uint32), whole.image.reshape(-1, 4)[some].view(np.uint32))
+    assert np.array_equal(part.rngs.reshape(-1, 2)[some], whole.rngs.reshape(-1, 2)[some])
+    assert not part.image.reshape(-1, 4)[rest].any() and np.array_equal(part.rngs.reshape(-1, 2)[rest], seed.rngs.reshape(-1, 2)[rest])
+    assert part.samples == 2

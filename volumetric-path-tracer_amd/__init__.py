@@ -102,6 +102,12 @@ hip.vpt_resolve_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
 hip.vpt_last_kernel_ms.argtypes = [_p, C.POINTER(C.c_float)]
 hip.vpt_intersect.argtypes = [_p, C.c_int, _p, C.c_int, _p, _p]
 hip.vpt_last_wave_costs.argtypes = [_p, _p, C.c_int, C.POINTER(C.c_int)]
+hip.vpt_multi_create.argtypes = [_p, C.POINTER(C.c_int), C.c_int, C.POINTER(_p)]
+hip.vpt_multi_destroy.argtypes = [_p]
+hip.vpt_multi_destroy.restype = None
+hip.vpt_multi_device_count.argtypes = [_p]
+hip.vpt_multi_render.argtypes = [_p, C.POINTER(VptParams), C.c_int, C.c_int, C.c_int, _p, _p, _p, C.POINTER(C.c_int)]
+hip.vpt_multi_get_render.argtypes = [_p, _p]
 hip.vpt_resolve_srgb8_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
 hip.vpt_selftest_reciprocal.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
 hip.vpt_selftest_light_cdf.argtypes = [_p, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
@@ -252,6 +258,37 @@ class DeviceScene:
     def close(self) -> None:
         if getattr(self, "handle", None) and hip is not None:   # see HostScene.close
             hip.vpt_scene_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+class MultiDeviceScene:
+    """vpt_multi: the scene on several GPUs of this process, tiles dealt round-robin (include/vpt.h)."""
+
+    def __init__(self, scene: HostScene, devices):
+        self.host_scene = scene
+        devs = (C.c_int * len(devices))(*devices)
+        out = _p()
+        _check(hip.vpt_multi_create(scene.desc, devs, len(devices), C.byref(out)), "vpt_multi_create")
+        self.handle = out
+
+    def pathtrace_samples(self, state: PathtraceState, params: PathtraceParams, count: int = 1) -> None:
+        abi = params.to_abi()
+        samples = C.c_int(state.samples)
+        _check(hip.vpt_multi_render(self.handle, C.byref(abi), count, state.width, state.height, state.image.ctypes.data,
+                                    state.hits.ctypes.data, state.rngs.ctypes.data, C.byref(samples)), "vpt_multi_render")
+        state.samples = samples.value
+
+    def get_render(self, width: int, height: int) -> np.ndarray:
+        out = np.zeros((height, width, 4), np.float32)
+        _check(hip.vpt_multi_get_render(self.handle, out.ctypes.data), "vpt_multi_get_render")
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "handle", None) and hip is not None:
+            hip.vpt_multi_destroy(self.handle)
         self.handle = None
 
     def __del__(self):

@@ -89,16 +89,20 @@ __global__ void vpt_reciprocal_selftest_kernel(unsigned long long* out) {
   if (skipped) atomicAdd(&out[1], skipped);
 }
 
+static std::string& g_error_text() {   // the message of the last failure on the calling thread (vpt_last_error)
+  thread_local std::string text;
+  return text;
+}
+
 namespace {
 
-thread_local std::string g_error;
 int fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  g_error = buf;
+  g_error_text() = buf;
   return code;
 }
 #define HIP_TRY(expr)                                                                              \
@@ -207,6 +211,17 @@ int bvh_depth(const vpt_bvh_node* nodes, int count, int root, int depth, int lim
 }
 
 }  // namespace
+
+// the same for the other translation units of the library (vpt_multi.cpp)
+int vpt_set_error(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error_text() = buf;
+  return code;
+}
 
 struct vpt_scene {
   int                device = 0;
@@ -396,7 +411,7 @@ int make_dparams(const vpt_params* p, const vpt_layout* l, int nsamples, DParams
 
 extern "C" {
 
-const char* vpt_last_error(void) { return g_error.c_str(); }
+const char* vpt_last_error(void) { return g_error_text().c_str(); }
 const char* vpt_version(void) { return "vpt-mi355x 0.1 (gfx950)"; }
 
 int vpt_device_count(void) {
@@ -430,6 +445,7 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   int ndev = vpt_device_count();
   if (ndev <= 0) return fail(VPT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(VPT_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
+  (void)hipGetLastError();   // start from a clean slate: an error left behind by an unrelated earlier call is not this call's
   HIP_TRY(hipSetDevice(device));
   const vpt_scene_desc& d = *desc;
   vpt_scene* s = new vpt_scene{};

@@ -218,7 +218,11 @@ typedef struct vpt_params {
   int32_t spheretrace_maxiter;
 } vpt_params;
 
-typedef struct vpt_scene vpt_scene; /* opaque device-side scene */
+/* Opaque device-side scene.  NOT thread-safe: a handle carries the launch schedule and staging buffers of its last
+ * call, so calls on ONE handle must not overlap (the reference serialises its own calls the same way);
+ * different handles may be used from different threads.  Launches on one handle may move between streams: the schedule
+ * tables written on the previous launch's stream are waited for. */
+typedef struct vpt_scene vpt_scene;
 
 /* How pixels are laid out in device-resident state and shared between GPUs.
  * The image is cut into tile_w x tile_h pixel tiles (row-major tile order); tile t belongs

@@ -32,6 +32,10 @@
 
 using namespace yocto;
 
+#ifdef VPT_DROPIN
+namespace yocto { extern std::string vpt_dropin_scene_file; }   // the drop-in binding's one hook (oracle/ref_dropin_stub.h)
+#endif
+
 static uint64_t fnv1a(const void* data, size_t nbytes) {
   auto p = (const unsigned char*)data;
   auto h = 0xcbf29ce484222325ull;
@@ -92,13 +96,20 @@ int main(int argc, const char** argv) {
   auto error = std::string{};
   auto scene = scene_data{};
   if (!load_scene(scene_name, scene, error)) die(error);
+#ifdef VPT_DROPIN
+  yocto::vpt_dropin_scene_file = scene_name;   // the one line the binding asks of the application (SDF type tags)
+#endif
   tesselate_surfaces(scene);
   auto bvh    = make_bvh(scene, params);
   auto lights = make_lights(scene, params);
   auto state  = make_state(scene, params);
   auto t1     = clk::now();
-  for (auto sample = 0; sample < params.samples; sample++)
-    pathtrace_samples(state, scene, bvh, lights, params);
+  try {
+    for (auto sample = 0; sample < params.samples; sample++)
+      pathtrace_samples(state, scene, bvh, lights, params);
+  } catch (const std::exception& e) {   // handle_errors of the reference's application (yocto_cli.h:364-390)
+    die(e.what());
+  }
   auto t2 = clk::now();
   auto setup_s  = std::chrono::duration<double>(t1 - t0).count();
   auto render_s = std::chrono::duration<double>(t2 - t1).count();

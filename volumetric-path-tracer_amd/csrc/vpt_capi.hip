@@ -386,6 +386,12 @@ int validate(const vpt_scene_desc& d) {
   }
   if (int rc = check_nodes(d.scene_bvh_nodes, d.num_scene_bvh_nodes, d.num_scene_bvh_prims, "scene")) return rc;
   for (int i = 0; i < d.num_scene_bvh_prims; i++) REQUIRE(d.scene_bvh_prims[i] >= 0 && d.scene_bvh_prims[i] < d.num_instances, "scene bvh: bad instance id");
+  {   // the single-instance query of the mesh-light pdf walk enters an instance through its scene-BVH slot
+    std::vector<char> in_bvh((size_t)d.num_instances, 0);
+    for (int i = 0; i < d.num_scene_bvh_prims; i++) in_bvh[(size_t)d.scene_bvh_prims[i]] = 1;
+    for (int i = 0; i < d.num_lights; i++)
+      if (d.lights[i].instance >= 0) REQUIRE(in_bvh[(size_t)d.lights[i].instance], "light %d: its instance is not in the scene bvh", i);
+  }
   return VPT_OK;
 }
 
@@ -548,7 +554,10 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
         scene_depth, max_shape_depth, scene_need4, max_shape_need4, s->stack_lds4, s->stack_spill4);
 
   for (int i = 0; i < d.num_lights; i++)
-    if (d.lights[i].instance >= 0 && shapes[(size_t)d.instances[d.lights[i].instance].shape].root_ref >= 0) s->large_mesh_lights = true;
+    if (d.lights[i].instance >= 0) {
+      int ref = shapes[(size_t)d.instances[d.lights[i].instance].shape].root_ref;
+      if (ref >= 0 || ((~ref) & 15) > 4) s->large_mesh_lights = true;
+    }
   std::vector<DInstance> instances((size_t)d.num_instances);
   for (int i = 0; i < d.num_instances; i++) {
     hframe f = to_h(d.instances[i].frame);
@@ -676,8 +685,11 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
       if (l.instance != VPT_INVALID) {
         const DInstance& in = instances[(size_t)l.instance];
         const DShape&    sh = shapes[(size_t)in.shape];
-        kind  = sh.root_ref < 0 ? VPT_LIGHT_SMALL_MESH : VPT_LIGHT_LARGE_MESH;
-        count = sh.root_ref < 0 ? ((~sh.root_ref) & 15) : 0;
+        // a shape whose BVH is one leaf of <= 4 primitives (the reference's bvh_max_prims) is walked inline from the light's own
+        // copy of them (light_prims holds four); anything else goes through the traversal
+        bool small = sh.root_ref < 0 && ((~sh.root_ref) & 15) <= 4;
+        kind  = small ? VPT_LIGHT_SMALL_MESH : VPT_LIGHT_LARGE_MESH;
+        count = small ? ((~sh.root_ref) & 15) : 0;
         for (int k = 0; k < 3; k++) r[k] = in.inv[k], r[3 + k] = in.fwd[k];
         r[6] = make_float4(sh.root_box[0], sh.root_box[1], sh.root_box[2], total);
         r[7] = make_float4(sh.root_box[3], sh.root_box[4], sh.root_box[5], 0);
@@ -854,47 +866,68 @@ static int permute(const vpt_layout* layout, int to_tiles, void* t_image, void* 
   return VPT_OK;
 }
 
+// row-major device staging of one frame for the host <-> tile-major conversions: borrowed from the scene handle where there is
+// one (vpt_render: allocated once per frame size), else allocated for the call; released on every path
+struct row_staging {
+  void *image = nullptr, *hits = nullptr, *rng = nullptr;
+  bool  owned = false;
+  ~row_staging() {
+    if (owned)
+      for (void* p : {image, hits, rng})
+        if (p) (void)hipFree(p);
+  }
+  int allocate(size_t pixels) {
+    owned = true;
+    HIP_TRY(hipMalloc(&image, pixels * 16));
+    HIP_TRY(hipMalloc(&hits, pixels * 4));
+    HIP_TRY(hipMalloc(&rng, pixels * 16));
+    return VPT_OK;
+  }
+};
+static int state_upload(const vpt_layout* layout, const float* image_rgba, const int32_t* hits, const uint64_t* rng,
+    void* d_image, void* d_hits, void* d_rng, hipStream_t st, row_staging& rows) {
+  size_t n = (size_t)layout->width * layout->height;
+  if (!rows.image)
+    if (int rc = rows.allocate(n)) return rc;
+  HIP_TRY(hipMemcpyAsync(rows.image, image_rgba, n * 16, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(rows.hits, hits, n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(rows.rng, rng, n * 16, hipMemcpyHostToDevice, st));
+  if (int rc = permute(layout, 1, d_image, d_hits, d_rng, rows.image, rows.hits, rows.rng, st)) return rc;
+  HIP_TRY(hipStreamSynchronize(st));
+  return VPT_OK;
+}
+static int state_download(const vpt_layout* layout, const void* d_image, const void* d_hits, const void* d_rng,
+    float* image_rgba, int32_t* hits, uint64_t* rng, hipStream_t st, row_staging& rows, bool rows_hold_the_frame) {
+  size_t n = (size_t)layout->width * layout->height;
+  if (!rows.image)
+    if (int rc = rows.allocate(n)) return rc;
+  if (!rows_hold_the_frame) {   // start from the caller's arrays so that pixels owned by other ranks keep their values
+    HIP_TRY(hipMemcpyAsync(rows.image, image_rgba, n * 16, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rows.hits, hits, n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rows.rng, rng, n * 16, hipMemcpyHostToDevice, st));
+  }
+  if (int rc = permute(layout, 0, (void*)d_image, (void*)d_hits, (void*)d_rng, rows.image, rows.hits, rows.rng, st)) return rc;
+  HIP_TRY(hipMemcpyAsync(image_rgba, rows.image, n * 16, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hits, rows.hits, n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(rng, rows.rng, n * 16, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return VPT_OK;
+}
+
 int vpt_state_upload(const vpt_layout* layout, const float* image_rgba, const int32_t* hits, const uint64_t* rng,
     void* d_image, void* d_hits, void* d_rng, void* stream) {
   if (!layout || !image_rgba || !hits || !rng || !d_image || !d_hits || !d_rng) return fail(VPT_ERR_INVALID_ARG, "null argument");
-  size_t n = (size_t)layout->width * layout->height;
-  void *ri = nullptr, *rh = nullptr, *rr = nullptr;
-  HIP_TRY(hipMalloc(&ri, n * 16));
-  HIP_TRY(hipMalloc(&rh, n * 4));
-  HIP_TRY(hipMalloc(&rr, n * 16));
-  int rc = VPT_OK;
-  hipStream_t st = (hipStream_t)stream;
-  if (hipMemcpyAsync(ri, image_rgba, n * 16, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(rh, hits, n * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(rr, rng, n * 16, hipMemcpyHostToDevice, st) != hipSuccess)
-    rc = fail(VPT_ERR_HIP, "state upload failed");
-  if (rc == VPT_OK) rc = permute(layout, 1, d_image, d_hits, d_rng, ri, rh, rr, st);
-  (void)hipStreamSynchronize(st);
-  (void)hipFree(ri), (void)hipFree(rh), (void)hipFree(rr);
-  return rc;
+  if (layout->width <= 0 || layout->height <= 0) return fail(VPT_ERR_INVALID_ARG, "bad layout");
+  row_staging rows;
+  return state_upload(layout, image_rgba, hits, rng, d_image, d_hits, d_rng, (hipStream_t)stream, rows);
 }
 
 int vpt_state_download(const vpt_layout* layout, const void* d_image, const void* d_hits, const void* d_rng,
     float* image_rgba, int32_t* hits, uint64_t* rng, void* stream) {
   if (!layout || !image_rgba || !hits || !rng || !d_image || !d_hits || !d_rng) return fail(VPT_ERR_INVALID_ARG, "null argument");
-  size_t n = (size_t)layout->width * layout->height;
-  void *ri = nullptr, *rh = nullptr, *rr = nullptr;
-  HIP_TRY(hipMalloc(&ri, n * 16));
-  HIP_TRY(hipMalloc(&rh, n * 4));
-  HIP_TRY(hipMalloc(&rr, n * 16));
-  hipStream_t st = (hipStream_t)stream;
-  int rc = VPT_OK;
-  // start from the caller's arrays so pixels owned by other ranks keep their values
-  if (hipMemcpyAsync(ri, image_rgba, n * 16, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(rh, hits, n * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(rr, rng, n * 16, hipMemcpyHostToDevice, st) != hipSuccess)
-    rc = fail(VPT_ERR_HIP, "state staging failed");
-  if (rc == VPT_OK) rc = permute(layout, 0, (void*)d_image, (void*)d_hits, (void*)d_rng, ri, rh, rr, st);
-  if (rc == VPT_OK &&
-      (hipMemcpyAsync(image_rgba, ri, n * 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(hits, rh, n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-          hipMemcpyAsync(rng, rr, n * 16, hipMemcpyDeviceToHost, st) != hipSuccess))
-    rc = fail(VPT_ERR_HIP, "state download failed");
-  if (hipStreamSynchronize(st) != hipSuccess && rc == VPT_OK) rc = fail(VPT_ERR_HIP, "stream synchronize failed");
-  (void)hipFree(ri), (void)hipFree(rh), (void)hipFree(rr);
-  return rc;
+  if (layout->width <= 0 || layout->height <= 0) return fail(VPT_ERR_INVALID_ARG, "bad layout");
+  row_staging rows;
+  return state_download(layout, d_image, d_hits, d_rng, image_rgba, hits, rng, (hipStream_t)stream, rows, false);
 }
 
 }  // extern "C"
@@ -1183,16 +1216,23 @@ int vpt_render(vpt_scene* s, const vpt_params* params, int nsamples, int width, 
   long long  slots = vpt_layout_slots(&lay), pixels = (long long)width * height;
   if (slots < 0) return VPT_ERR_INVALID_ARG;
   if (s->staged_slots != slots || s->staged_pixels != pixels) {
-    for (void** p : {&s->s_image, &s->s_hits, &s->s_rng})
+    for (void** p : {&s->s_image, &s->s_hits, &s->s_rng, &s->r_image, &s->r_hits, &s->r_rng})
       if (*p) (void)hipFree(*p), *p = nullptr;
+    s->staged_slots = s->staged_pixels = 0;
     HIP_TRY(hipMalloc(&s->s_image, (size_t)slots * 16));
     HIP_TRY(hipMalloc(&s->s_hits, (size_t)slots * 4));
     HIP_TRY(hipMalloc(&s->s_rng, (size_t)slots * 16));
+    HIP_TRY(hipMalloc(&s->r_image, (size_t)pixels * 16));
+    HIP_TRY(hipMalloc(&s->r_hits, (size_t)pixels * 4));
+    HIP_TRY(hipMalloc(&s->r_rng, (size_t)pixels * 16));
     s->staged_slots = slots, s->staged_pixels = pixels;
   }
-  if (int rc = vpt_state_upload(&lay, image_rgba, hits, rng, s->s_image, s->s_hits, s->s_rng, nullptr)) return rc;
+  row_staging rows;   // the handle's buffers: allocated once per frame size, not per call
+  rows.image = s->r_image, rows.hits = s->r_hits, rows.rng = s->r_rng;
+  if (int rc = state_upload(&lay, image_rgba, hits, rng, s->s_image, s->s_hits, s->s_rng, nullptr, rows)) return rc;
   if (int rc = vpt_render_device(s, params, &lay, todo, s->s_image, s->s_hits, s->s_rng, nullptr)) return rc;
-  if (int rc = vpt_state_download(&lay, s->s_image, s->s_hits, s->s_rng, image_rgba, hits, rng, nullptr)) return rc;
+  // the row-major staging still holds the frame that was uploaded, and this single-rank layout owns every pixel
+  if (int rc = state_download(&lay, s->s_image, s->s_hits, s->s_rng, image_rgba, hits, rng, nullptr, rows, true)) return rc;
   if (int rc = check_watchdog(s)) return rc;
   *samples_io += todo;
   return VPT_OK;

@@ -170,6 +170,9 @@ void pathtrace_samples(pathtrace_state& state, const scene_data& scene, const bv
 void pathtrace_samples(pathtrace_state& state, const scene_data& scene, const bvh_scene& bvh,
     const pathtrace_lights& lights, const pathtrace_params& params, int count);
 void pathtrace_release(const scene_data& scene);  // drop the cached device copy of `scene`
+// Extension: the GPUs pathtrace_samples renders on (default {0}).  With more than one, the frame's 8x8 tiles are dealt
+// round-robin to them (vpt_multi of include/vpt.h); the result does not depend on the list.  Drops the cached copies.
+void pathtrace_set_devices(const vector<int>& devices);
 color_image get_render(const pathtrace_state& state);
 void        get_render(color_image& render, const pathtrace_state& state);
 
@@ -201,6 +204,8 @@ bool load_shape(const string& filename, shape_data& shape, string& error, bool f
 bool load_texture(const string& filename, texture_data& texture, string& error);
 bool load_volume(const string& filename, volume_data& vol, bool binary, string& error);
 bool save_image(const string& filename, const color_image& image, string& error);
+// the members of a --config file (yocto_cli.cpp:912-945) as (option name, value text) pairs
+bool load_cli_config(const string& filename, vector<std::pair<string, string>>& options, string& error);
 // output quantisation (yocto_color.h:207-231, yocto_image.cpp:870-874)
 vector<vec4b> linear_to_srgb8(const color_image& image);
 // bit-faithful restatement of the reference's baseline JPEG writer at quality 75

@@ -381,19 +381,52 @@ void flatten_scene(flat_scene& flat, const scene_data& scene, const bvh_scene& b
 }
 
 // =============================================================================================
-// pathtrace_samples — the drop-in.  Device copies of scenes are cached per scene_data address.
+// pathtrace_samples — the drop-in.  Device copies of scenes are cached per scene_data address + content fingerprint.
 // =============================================================================================
 namespace {
+// The reference's API has no release hook and keys nothing: a caller may mutate the scene, rebuild bvh / lights or
+// allocate another scene at the same address between two calls.  The cached device copy therefore carries a cheap
+// fingerprint of what it was made from (addresses and sizes of the containers the flattening reads, a hash over the
+// heads of the big arrays); a mismatch rebuilds it.
 struct device_entry {
-  vpt_scene* handle = nullptr;
+  vpt_multi* handle = nullptr;
+  uint64_t   fingerprint = 0;
   ~device_entry() {
-    if (handle) vpt_scene_destroy(handle);
+    if (handle) vpt_multi_destroy(handle);
   }
 };
 std::mutex                                                   cache_mutex;
 std::map<const scene_data*, std::unique_ptr<device_entry>>& device_cache() {
   static auto cache = std::map<const scene_data*, std::unique_ptr<device_entry>>{};
   return cache;
+}
+vector<int>& device_list() {
+  static auto devices = vector<int>{0};
+  return devices;
+}
+uint64_t mix(uint64_t h, uint64_t v) { return (h ^ v) * 0x100000001b3ull; }
+template <typename T>
+uint64_t mix_array(uint64_t h, const vector<T>& v) {
+  h = mix(mix(h, (uint64_t)(uintptr_t)v.data()), v.size());
+  auto bytes = (const unsigned char*)v.data();
+  auto n     = v.size() * sizeof(T);
+  for (size_t i = 0; i < n && i < 256; i++) h = mix(h, bytes[i]);          // head
+  for (size_t i = n > 256 ? n - 256 : n; i < n; i++) h = mix(h, bytes[i]);  // tail
+  return h;
+}
+uint64_t scene_fingerprint(const scene_data& scene, const bvh_scene& bvh, const pathtrace_lights& lights) {
+  auto h = 0xcbf29ce484222325ull;
+  h = mix_array(h, scene.cameras), h = mix_array(h, scene.instances), h = mix_array(h, scene.materials);
+  h = mix_array(h, scene.environments), h = mix_array(h, scene.vol_instances), h = mix_array(h, scene.sdfs);
+  h = mix(h, scene.shapes.size()), h = mix(h, scene.textures.size()), h = mix(h, scene.volumes.size());
+  for (auto& s : scene.shapes) h = mix_array(h, s.positions), h = mix(h, s.triangles.size()), h = mix(h, s.quads.size());
+  for (auto& t : scene.textures) h = mix(mix(h, (uint64_t)t.width), (uint64_t)t.height), h = mix_array(h, t.pixelsb), h = mix_array(h, t.pixelsf);
+  for (auto& v : scene.volumes) h = mix_array(h, v.vol);
+  h = mix_array(h, bvh.nodes), h = mix_array(h, bvh.primitives), h = mix(h, bvh.shapes.size());
+  for (auto& b : bvh.shapes) h = mix_array(h, b.nodes);
+  h = mix(h, lights.lights.size());
+  for (auto& l : lights.lights) h = mix(mix(mix(h, (uint64_t)l.instance), (uint64_t)l.environment), (uint64_t)l.sdf), h = mix_array(h, l.elements_cdf);
+  return h;
 }
 }  // namespace
 
@@ -402,30 +435,40 @@ void pathtrace_release(const scene_data& scene) {
   device_cache().erase(&scene);
 }
 
+void pathtrace_set_devices(const vector<int>& devices) {
+  if (devices.empty()) throw std::invalid_argument{"empty device list"};
+  auto lock = std::lock_guard{cache_mutex};
+  device_list() = devices;
+  device_cache().clear();
+}
+
 void pathtrace_samples(pathtrace_state& state, const scene_data& scene, const bvh_scene& bvh,
     const pathtrace_lights& lights, const pathtrace_params& params, int count) {
   if (state.samples >= params.samples) return;  // reference cpp:1055
   if ((int)params.shader < 0 || (int)params.shader > (int)pathtrace_shader_type::implicit_normal)
     throw std::runtime_error{"sampler unknown"};  // reference cpp:947-950
-  auto handle = (vpt_scene*)nullptr;
+  auto handle = (vpt_multi*)nullptr;
   {
     auto  lock  = std::lock_guard{cache_mutex};
     auto& entry = device_cache()[&scene];
-    if (!entry) {
+    auto  print = scene_fingerprint(scene, bvh, lights);
+    if (!entry || entry->fingerprint != print) {
+      entry.reset();
       auto flat = flat_scene{};
       flatten_scene(flat, scene, bvh, lights);
       auto fresh = std::make_unique<device_entry>();
-      if (vpt_scene_create(&flat.desc, 0, &fresh->handle) != VPT_OK) {
+      if (vpt_multi_create(&flat.desc, device_list().data(), (int)device_list().size(), &fresh->handle) != VPT_OK) {
         device_cache().erase(&scene);
-        throw std::runtime_error{string{"vpt_scene_create: "} + vpt_last_error()};
+        throw std::runtime_error{string{"vpt_multi_create: "} + vpt_last_error()};
       }
-      entry = std::move(fresh);
+      fresh->fingerprint = print;
+      entry              = std::move(fresh);
     }
     handle = entry->handle;
   }
   auto abi = to_abi(params);
   static_assert(sizeof(rng_state) == 16 && sizeof(vec4f) == 16, "state layout");
-  if (vpt_render(handle, &abi, count, state.width, state.height, (float*)state.image.data(),
+  if (vpt_multi_render(handle, &abi, count, state.width, state.height, (float*)state.image.data(),
           state.hits.data(), (uint64_t*)state.rngs.data(), &state.samples) != VPT_OK)
     throw std::runtime_error{string{"vpt_render: "} + vpt_last_error()};
 }

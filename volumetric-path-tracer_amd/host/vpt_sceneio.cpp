@@ -863,4 +863,42 @@ bool save_image(const string& filename, const color_image& image, string& error)
   return true;
 }
 
+// A --config file of the reference's command line (yocto_cli.cpp:912-945): one JSON object whose members are option
+// values.  Returned as (name, text) pairs - strings as they are, numbers printed, booleans "true" / "false" - for the
+// application's own option table to validate.
+bool load_cli_config(const string& filename, vector<std::pair<string, string>>& options, string& error) {
+  auto data = vector<uint8_t>{};
+  auto ioerror = string{};
+  if (!read_file(filename, data, ioerror)) {
+    error = "missing configuration file " + filename;
+    return false;
+  }
+  auto js = json_value{};
+  try {
+    auto parser = json_parser{(const char*)data.data(), (const char*)data.data() + data.size()};
+    js          = parser.parse();
+  } catch (const std::exception&) {
+    error = "error converting configuration " + filename;
+    return false;
+  }
+  if (js.kind != json_value::object_k) {
+    error = "error converting configuration " + filename;
+    return false;
+  }
+  for (auto& [key, v] : js.members) {
+    char buf[64];
+    switch (v.kind) {
+      case json_value::string_k: options.emplace_back(key, v.text); break;
+      case json_value::bool_k: options.emplace_back(key, v.boolean ? "true" : "false"); break;
+      case json_value::number_k:
+        if (v.number == (double)(long long)v.number) snprintf(buf, sizeof(buf), "%lld", (long long)v.number);
+        else snprintf(buf, sizeof(buf), "%.17g", v.number);
+        options.emplace_back(key, buf);
+        break;
+      default: error = "bad value for " + key; return false;
+    }
+  }
+  return true;
+}
+
 }  // namespace vpt

@@ -73,3 +73,11 @@ def test_reference_application_writes_the_references_jpeg(tmp_path):
     rms = np.sqrt(np.mean((a - b) ** 2, axis=(0, 1)))
     print("drop-in JPEG per-channel RMS:", rms, "byte-identical:", open(out, "rb").read() == open(gold, "rb").read())
     assert a.shape == b.shape and (rms <= 2e-3).all()
+
+
+def test_integration_md_shows_the_compiled_stub_verbatim():
+    """what INTEGRATION.md presents as the reference-side binding is the very file oracle/Makefile compiles; no elisions"""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = open(os.path.join(ROOT, "oracle", "ref_dropin_stub.h")).read()
+    assert stub in md
+    assert "/* ..." not in md and "/*..." not in md

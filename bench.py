@@ -202,17 +202,22 @@ def main():
         per_launch_samples = samples_per_step / world
         mean_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         achieved = bps * per_launch_samples / (mean_ms * 1e-3) * 1e-9
-        # memory-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
-        # runs of this same command); only quoted for the workload it was measured on
+        # memory-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs of
+        # this same command, profiles/tools/profile_config.sh); only quoted for the workload it was measured on
         traffic = None
-        def _version(path):   # profiles/r<round>_v<version>_hbm_traffic.json, compared numerically
+        tag = {("03_volume", "volpathtrace", 64): "k1", ("05_head1ss_sub", "volpathtrace", 64): "head",
+               ("06_gridsdf_synth", "implicit", 4): "k2"}.get((scene_name, args.shader, args.bounces))
+
+        def _version(path):   # profiles/r<round>_<tag>_v<version>_hbm_traffic.json (round 1: r01_v<version>_...), compared numerically
             import re
-            m = re.search(r"r(\d+)_v(\d+)_", os.path.basename(path))
+            m = re.search(r"r(\d+)_(?:[a-z0-9]+_)?v(\d+)_", os.path.basename(path))
             return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), key=_version)   # latest passes
-        tfile = tfiles[-1] if tfiles else ""
-        if tfile and args.scene == SCENE and args.shader == "volpathtrace" and args.bounces == 64:
-            traffic = round(json.load(open(tfile))["bytes_per_sample"] * per_launch_samples)
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_v*_hbm_traffic.json")) +
+                        (glob.glob(os.path.join(ROOT, "profiles", "r01_v*_hbm_traffic.json")) if tag == "k1" else []), key=_version) if tag else []
+        if tfiles:
+            t = json.load(open(tfiles[-1]))
+            if t.get("bytes_per_sample"):
+                traffic = round(t["bytes_per_sample"] * per_launch_samples)
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel": ("vpt_render_kernel<%s>" if args.shader.startswith("implicit") else "vpt_mesh_kernel<%s>") % args.shader, "kernel_ms": round(mean_ms, 3),

@@ -1383,6 +1383,10 @@ int vpt_debug_wave_times(unsigned long long* out, int nwaves) {
   HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vpt_wave_times), sizeof(unsigned long long) * 2 * (size_t)nwaves));
   return VPT_OK;
 }
+int vpt_debug_wave_hw(unsigned* out, int nwaves) {
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vpt_wave_hw), sizeof(unsigned) * (size_t)nwaves));
+  return VPT_OK;
+}
 #endif
 
 #ifdef VPT_K2_STATS

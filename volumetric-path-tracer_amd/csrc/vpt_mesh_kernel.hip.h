@@ -491,6 +491,7 @@ enum { ST_NEW = 0, ST_MAIN = 1, ST_LPDF = 2 };
 #ifdef VPT_WAVE_TIMES
 // diagnostic build: start / end of every wave on the 100 MHz wall clock, to draw the launch's occupancy timeline
 __device__ unsigned long long g_vpt_wave_times[2 * 65536];
+__device__ unsigned g_vpt_wave_hw[65536];   // XCC_ID << 16 | HW_ID[15:0] (wave, simd, pipe, cu, sh, se)
 #endif
 
 template <int SH, bool SPILL>
@@ -792,7 +793,13 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
     unsigned long long dt = clock_ticks(__float_as_int(acc.x)) - wave_start;   // after the last sample was accumulated
     sched.cost[wave] = dt < 0xffffffffull ? (unsigned)dt : 0xffffffffu;
 #ifdef VPT_WAVE_TIMES
-    if (wave < 65536) g_vpt_wave_times[2 * wave] = wave_start, g_vpt_wave_times[2 * wave + 1] = wave_start + dt;
+    if (wave < 65536) {
+      g_vpt_wave_times[2 * wave] = wave_start, g_vpt_wave_times[2 * wave + 1] = wave_start + dt;
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_vpt_wave_hw[wave] = (xcc & 0xf) << 16 | (hw & 0xffff);
+    }
 #endif
   }
 }

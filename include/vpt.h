@@ -319,6 +319,14 @@ int vpt_last_wave_costs(vpt_scene* scene, unsigned* ticks, int capacity, int* co
  * tracing rarely produces (axis-aligned, grazing a box plane, denormal direction components). */
 int vpt_intersect(vpt_scene* scene, int n, const float* rays, int instance, int32_t* ids, float* uvt);
 
+/* build_bvh(bvh, bboxes, highquality = false) of the reference (libs/yocto/yocto_bvh.cpp:447-507, split_middle
+ * :411-441) on the device: `n` boxes {min.xyz, max.xyz} in, the reference's node array and primitive order out - the
+ * same nodes under the same ids, the same primitive permutation, the same float bits (the reference's build is depth
+ * first over a stack with std::partition; csrc/vpt_bvh_build.hip says how a level-parallel build arrives at the same
+ * arrays).  nodes: room for `capacity` >= max(1, 2 n - 1) entries; *num_nodes = entries written; primitives: n ints.
+ * Synchronous.  SURVEY §8(f) row 4 (load-time callers of the hot path). */
+int vpt_build_bvh(int device, const float* bboxes, int n, vpt_bvh_node* nodes, int capacity, int* num_nodes, int32_t* primitives);
+
 /* Device self-test of an arithmetic shortcut the kernels rely on for bit-exact parity: the reference divides
  * (1 / d per ray, yocto_bvh.cpp:806-808; 1 / det per triangle, yocto_geometry.h:690), the kernels use
  * v_rcp_f32 + one Newton step where every lane's operand has a biased exponent in 1..250.  Runs all 2^32 bit

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+from typing import Optional
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -101,6 +102,7 @@ hip.vpt_render_device.argtypes = [_p, C.POINTER(VptParams), C.POINTER(VptLayout)
 hip.vpt_resolve_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
 hip.vpt_last_kernel_ms.argtypes = [_p, C.POINTER(C.c_float)]
 hip.vpt_intersect.argtypes = [_p, C.c_int, _p, C.c_int, _p, _p]
+hip.vpt_build_bvh.argtypes = [C.c_int, _p, C.c_int, _p, C.c_int, C.POINTER(C.c_int), _p]
 hip.vpt_last_wave_costs.argtypes = [_p, _p, C.c_int, C.POINTER(C.c_int)]
 hip.vpt_multi_create.argtypes = [_p, C.POINTER(C.c_int), C.c_int, C.POINTER(_p)]
 hip.vpt_multi_destroy.argtypes = [_p]
@@ -124,6 +126,8 @@ host.vpth_scene_desc.restype = _p
 host.vpth_state_size.argtypes = [_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 host.vpth_make_state.argtypes = [_p, C.c_int, C.c_int, _p, _p, _p]
 host.vpth_scene_stats.argtypes = [_p, C.c_char_p, C.c_int]
+host.vpth_scene_rebuild_bvh_device.argtypes = [_p, C.c_int, C.c_char_p, C.c_int]
+host.vpth_build_bvh_host.argtypes = [_p, C.c_int, _p, C.POINTER(C.c_int), _p]
 host.vpth_linear_to_srgb8.argtypes = [C.c_int, C.c_int, _p, C.c_int, _p]
 host.vpth_linear_to_srgb8.restype = None
 host.vpth_encode_jpeg_q75.argtypes = [C.c_int, C.c_int, _p, _p, C.c_int64]
@@ -139,15 +143,38 @@ def device_count() -> int:
     return hip.vpt_device_count()
 
 
+BVH_NODE = np.dtype([("bbox_min", np.float32, 3), ("bbox_max", np.float32, 3), ("start", np.int32), ("num", np.int16), ("axis", np.int8),
+                     ("internal", np.uint8)])
+assert BVH_NODE.itemsize == 32
+
+
+def build_bvh(bboxes: np.ndarray, device: Optional[int] = 0):
+    """build_bvh(bvh, bboxes, false) of the reference over n boxes {min.xyz, max.xyz}: (nodes, primitives).  device = GPU index
+    (vpt_build_bvh) or None for the host build the loader uses (same arrays)."""
+    bboxes = np.ascontiguousarray(bboxes, np.float32).reshape(-1, 6)
+    n = len(bboxes)
+    nodes = np.zeros(max(1, 2 * n), BVH_NODE)
+    prims = np.zeros(max(1, n), np.int32)
+    count = C.c_int()
+    if device is None:
+        host.vpth_build_bvh_host(bboxes.ctypes.data, n, nodes.ctypes.data, C.byref(count), prims.ctypes.data)
+    else:
+        _check(hip.vpt_build_bvh(device, bboxes.ctypes.data, n, nodes.ctypes.data, len(nodes), C.byref(count), prims.ctypes.data), "vpt_build_bvh")
+    return nodes[:count.value].copy(), prims[:n].copy()
+
+
 class HostScene:
     """load_scene + tesselate_surfaces + make_bvh + make_lights, flattened for the C-ABI."""
 
-    def __init__(self, filename: str):
+    def __init__(self, filename: str, bvh_device: Optional[int] = None):
+        """bvh_device: build the BVHs on that GPU (make_bvh_device / vpt_build_bvh) instead of on the host - same arrays"""
         err = C.create_string_buffer(1024)
         self.handle = host.vpth_scene_load(os.fsencode(filename), err, len(err))
         if not self.handle:
             raise VptError(err.value.decode())
         self.filename = filename
+        if bvh_device is not None and host.vpth_scene_rebuild_bvh_device(self.handle, bvh_device, err, len(err)) != 0:
+            raise VptError(err.value.decode())
 
     @property
     def desc(self) -> int:

@@ -158,6 +158,10 @@ struct color_image {
 
 pathtrace_state  make_state(const scene_data& scene, const pathtrace_params& params);
 bvh_scene        make_bvh(const scene_data& scene, const pathtrace_params& params);
+// Extension: the same trees (node for node, hash-equal) built on GPU `device` by vpt_build_bvh; throws if that fails.
+bvh_scene        make_bvh_device(const scene_data& scene, const pathtrace_params& params, int device = 0);
+// build_bvh over `n` boxes {min.xyz, max.xyz} on the host (what make_bvh runs per shape and for the instances)
+bvh_data         build_bvh_host(const float* bboxes, int n);
 pathtrace_lights make_lights(const scene_data& scene, const pathtrace_params& params);
 void             tesselate_surfaces(scene_data& scene);  // throws if the scene has subdivs
 // Progressively computes an image: ONE sample per pixel per call, on the GPU (vpt_render).

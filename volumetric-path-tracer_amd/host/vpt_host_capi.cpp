@@ -15,7 +15,7 @@ struct host_scene {
   scene_data       scene;
   bvh_scene        bvh;
   pathtrace_lights lights;
-  flat_scene       flat;
+  std::unique_ptr<flat_scene> flat = std::make_unique<flat_scene>();
 };
 void set_error(char* err, int errlen, const string& msg) {
   if (err && errlen > 0) snprintf(err, (size_t)errlen, "%s", msg.c_str());
@@ -41,14 +41,35 @@ void* vpth_scene_load(const char* filename, char* err, int errlen) {
     auto params = pathtrace_params{};
     h->bvh      = make_bvh(h->scene, params);
     h->lights   = make_lights(h->scene, params);
-    flatten_scene(h->flat, h->scene, h->bvh, h->lights);
+    flatten_scene(*h->flat, h->scene, h->bvh, h->lights);
     return h.release();
   } catch (const std::exception& e) {
     return set_error(err, errlen, e.what()), nullptr;
   }
 }
+// rebuild the scene's BVHs on GPU `device` (make_bvh_device) and flatten again; 0 on success
+int vpth_scene_rebuild_bvh_device(void* hh, int device, char* err, int errlen) {
+  try {
+    auto& h = *(host_scene*)hh;
+    h.bvh   = make_bvh_device(h.scene, pathtrace_params{}, device);
+    auto flat = std::make_unique<flat_scene>();
+    flatten_scene(*flat, h.scene, h.bvh, h.lights);
+    h.flat = std::move(flat);   // the address vpth_scene_desc handed out before is gone: callers fetch it again
+    return 0;
+  } catch (const std::exception& e) {
+    return set_error(err, errlen, e.what()), -1;
+  }
+}
+// build_bvh over n boxes on the host (the checker of vpt_build_bvh in tests): nodes has room for max(1, 2 n) entries
+int vpth_build_bvh_host(const float* bboxes, int n, vpt_bvh_node* nodes, int* num_nodes, int32_t* primitives) {
+  auto bvh = build_bvh_host(bboxes, n);
+  memcpy(nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(vpt_bvh_node));
+  if (n > 0) memcpy(primitives, bvh.primitives.data(), (size_t)n * sizeof(int32_t));
+  *num_nodes = (int)bvh.nodes.size();
+  return 0;
+}
 void vpth_scene_free(void* h) { delete (host_scene*)h; }
-const vpt_scene_desc* vpth_scene_desc(void* h) { return &((host_scene*)h)->flat.desc; }
+const vpt_scene_desc* vpth_scene_desc(void* h) { return &((host_scene*)h)->flat->desc; }
 
 // make_state dimensions (yocto_pathtrace.cpp:964-970)
 int vpth_state_size(void* h, int camera, int resolution, int* width, int* height) {

@@ -116,7 +116,27 @@ static void build_nodes(bvh_data& bvh, const vector<bbox3f>& bboxes) {
   bvh.nodes.shrink_to_fit();
 }
 
-static bvh_data make_shape_bvh(const shape_data& shape) {
+// the nodes of one tree: on the host (build_nodes) or on a GPU (vpt_build_bvh: the same arrays)
+static void build_nodes_on(int device, bvh_data& bvh, const vector<bbox3f>& bboxes) {
+  if (device < 0) return build_nodes(bvh, bboxes);
+  static_assert(sizeof(bbox3f) == 6 * sizeof(float), "bbox layout");
+  auto n = (int)bboxes.size(), count = 0;
+  bvh.nodes.assign((size_t)std::max(1, 2 * n), bvh_node{});
+  bvh.primitives.assign((size_t)n, 0);
+  if (vpt_build_bvh(device, (const float*)bboxes.data(), n, bvh.nodes.data(), (int)bvh.nodes.size(), &count, bvh.primitives.data()) != VPT_OK)
+    throw std::runtime_error{string{"make_bvh_device: "} + vpt_last_error()};
+  bvh.nodes.resize((size_t)count);
+  bvh.nodes.shrink_to_fit();
+}
+bvh_data build_bvh_host(const float* bboxes, int n) {
+  auto boxes = vector<bbox3f>((size_t)n);
+  if (n > 0) memcpy((void*)boxes.data(), bboxes, (size_t)n * sizeof(bbox3f));
+  auto bvh = bvh_data{};
+  build_nodes(bvh, boxes);
+  return bvh;
+}
+
+static bvh_data make_shape_bvh(const shape_data& shape, int device) {
   auto bvh    = bvh_data{};
   auto bboxes = vector<bbox3f>{};
   if (!shape.triangles.empty()) {
@@ -135,14 +155,14 @@ static bvh_data make_shape_bvh(const shape_data& shape) {
       bboxes[i] = {vmin(p0, vmin(p1, vmin(p2, p3))), vmax(p0, vmax(p1, vmax(p2, p3)))};
     }
   }
-  build_nodes(bvh, bboxes);
+  build_nodes_on(device, bvh, bboxes);
   return bvh;
 }
 
-bvh_scene make_bvh(const scene_data& scene, const pathtrace_params&) {
+static bvh_scene make_bvh_on(int device, const scene_data& scene) {
   auto bvh = bvh_data{};
   bvh.shapes.resize(scene.shapes.size());
-  for (size_t i = 0; i < scene.shapes.size(); i++) bvh.shapes[i] = make_shape_bvh(scene.shapes[i]);
+  for (size_t i = 0; i < scene.shapes.size(); i++) bvh.shapes[i] = make_shape_bvh(scene.shapes[i], device);
   auto bboxes = vector<bbox3f>(scene.instances.size());
   for (size_t i = 0; i < bboxes.size(); i++) {
     auto& instance = scene.instances[i];
@@ -159,8 +179,13 @@ bvh_scene make_bvh(const scene_data& scene, const pathtrace_params&) {
         }
     bboxes[i] = box;
   }
-  build_nodes(bvh, bboxes);
+  build_nodes_on(device, bvh, bboxes);
   return bvh;
+}
+bvh_scene make_bvh(const scene_data& scene, const pathtrace_params&) { return make_bvh_on(-1, scene); }
+bvh_scene make_bvh_device(const scene_data& scene, const pathtrace_params&, int device) {
+  if (device < 0) throw std::invalid_argument{"make_bvh_device: negative device"};
+  return make_bvh_on(device, scene);
 }
 
 void tesselate_surfaces(scene_data& scene) {

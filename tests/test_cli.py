@@ -100,3 +100,14 @@ def test_cli_without_a_gpu_fails_loudly(tmp_path):
         pytest.skip("a GPU is visible here")
     r = run("--scene", SCENE_03, "--samples", "1", "--resolution", "32", "--output", str(tmp_path / "x.png"))
     assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_gpubvh_renders_the_same_file(tmp_path):
+    """--gpubvh builds the BVHs with vpt_build_bvh instead of on the host: the same trees, hence the same bytes"""
+    a, b = str(tmp_path / "host.jpg"), str(tmp_path / "gpu.jpg")
+    common = ["--scene", SCENE_03, "--shader", "volpathtrace", "--samples", "4", "--resolution", "96", "--bounces", "64"]
+    for out, extra in ((a, []), (b, ["--gpubvh"])):
+        r = run(*common, "--output", out, *extra)
+        assert r.returncode == 0, r.stderr
+    assert open(a, "rb").read() == open(b, "rb").read()

@@ -80,19 +80,49 @@ __global__ void k_reset_keys(int lb, int le, tkeys* keys) {
   if (t >= le) return;
   for (int c = 0; c < 3; c++) keys[t].k[c] = keys[t].k[6 + c] = ~0ull, keys[t].k[3 + c] = keys[t].k[9 + c] = 0ull;
 }
-// bounds of every live node: each primitive position offers its box and its centre to its node
+// bounds of every live node: each primitive position offers its box and its centre to its node.  Positions of a node are
+// contiguous, so near the root all 64 lanes of a wave belong to the same node: they fold their keys across the wave first and
+// lane 0 makes the 12 atomic updates (without this the first levels serialise n atomics on 12 addresses).
+__device__ __forceinline__ unsigned long long wave_min(unsigned long long v) {
+  for (int m = 32; m >= 1; m >>= 1) {
+    unsigned long long o = __shfl_xor(v, m, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_max(unsigned long long v) {
+  for (int m = 32; m >= 1; m >>= 1) {
+    unsigned long long o = __shfl_xor(v, m, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
 __global__ void k_bounds(int n, const int* __restrict__ prims, const int* __restrict__ node_of, const float* __restrict__ bb,
     const float* __restrict__ ctr, tkeys* keys) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int t = node_of[i];
-  if (t < 0) return;
-  int p = prims[i];
+  int t = i < n ? node_of[i] : -1;
+  int t0 = __builtin_amdgcn_readfirstlane(t);
+  bool uniform = __builtin_amdgcn_ballot_w64(t != t0) == 0;   // the whole wave (blockDim is a multiple of 64) in one node
+  if (uniform && t0 < 0) return;
+  unsigned long long k[12];
+  if (t >= 0) {
+    int p = prims[i];
+    for (int c = 0; c < 3; c++) {
+      k[c]     = min_key(bb[6 * p + c], i);
+      k[3 + c] = max_key(bb[6 * p + 3 + c], i);
+      k[6 + c] = min_key(ctr[3 * p + c], i);
+      k[9 + c] = max_key(ctr[3 * p + c], i);
+    }
+  }
+  if (uniform) {
+    for (int c = 0; c < 3; c++) k[c] = wave_min(k[c]), k[3 + c] = wave_max(k[3 + c]), k[6 + c] = wave_min(k[6 + c]), k[9 + c] = wave_max(k[9 + c]);
+    if ((threadIdx.x & 63) != 0) return;
+  } else if (t < 0) return;
   for (int c = 0; c < 3; c++) {
-    atomicMin(&keys[t].k[c], min_key(bb[6 * p + c], i));
-    atomicMax(&keys[t].k[3 + c], max_key(bb[6 * p + 3 + c], i));
-    atomicMin(&keys[t].k[6 + c], min_key(ctr[3 * p + c], i));
-    atomicMax(&keys[t].k[9 + c], max_key(ctr[3 * p + c], i));
+    atomicMin(&keys[t].k[c], k[c]);
+    atomicMax(&keys[t].k[3 + c], k[3 + c]);
+    atomicMin(&keys[t].k[6 + c], k[6 + c]);
+    atomicMax(&keys[t].k[9 + c], k[9 + c]);
   }
 }
 // the node's box (bits of the winning elements) and split_middle's choice of axis and plane

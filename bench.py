@@ -58,7 +58,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step")
     ap.add_argument("--resolution", type=int, default=1280)
     ap.add_argument("--bounces", type=int, default=64)
@@ -254,7 +254,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": "f32", "data": data_desc,
             "config": {"workload": f"{scene_name} {args.shader} bounces={args.bounces} {width}x{height}x{args.spp}spp per step" + ("" if world == 1 else (", frame grows with N" if args.weak else ", fixed frame")),
-                       "tile": f"{args.tile}x{args.tile}", "parallelism": f"tiles%{world}" if world > 1 else "1gpu",
+                       "tile": f"{args.tile}x{args.tile}", "parallelism": f"tiles%{world}, costly tiles split into partly filled waves (auto)" if world > 1 else "1gpu",
                        "samples_per_step": samples_per_step},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -306,10 +306,18 @@ int vpt_resolve_srgb8_device(const vpt_layout* layout, const void* d_tiles_all_r
  * that has not finished after 300 s leaves the kernel instead of holding the GPU: a defect, never a workload). */
 int vpt_last_kernel_ms(vpt_scene* scene, float* ms);
 
-/* How long every wave of the last vpt_render_device launch on this scene ran, in ticks of the 100 MHz wall clock,
- * indexed by wave (wave w renders state slots 64 w .. 64 w + 63): what the next launch's longest-first order is made
- * from, exposed for load-balance analysis (critical path = the largest entry, work = their sum).  Synchronises with the
- * launch.  *count = waves of the launch; at most `capacity` entries are written. */
+/* How long every wave of the last vpt_render_device launch on this scene ran, in ticks of the 100 MHz wall clock:
+ * what the next launch's longest-first order is made from, exposed for load-balance analysis (critical path = the
+ * largest entry, slot time = their sum).  Wave w renders state slots 64 w .. 64 w + 63 - unless the launch split
+ * costly tiles into several partly filled waves (below), in which case the entries follow the split launch's waves.
+ * Synchronises with the launch.  *count = waves of the launch; at most `capacity` entries are written.
+ *
+ * Tile splitting.  A wave runs all samples of its pixels one after the other, so a launch is at least as long as its
+ * costliest tile.  When a layout shares the frame among ranks (nranks > 1) the work per GPU falls with N and that
+ * chain does not: from the second full call on a layout, the mesh kernels then run the costliest tiles as 2^k waves
+ * that hold every 2^k-th pixel (fewer live lanes diverge less: a wave with 8 lanes takes ~0.45 of the time), chosen
+ * once from the measured per-tile costs by simulating the launch's schedule.  Results do not depend on it (pixels own
+ * their RNG streams).  VPT_SPLIT=0 disables it, VPT_SPLIT=1 also considers it for nranks == 1 (never pays there). */
 int vpt_last_wave_costs(vpt_scene* scene, unsigned* ticks, int capacity, int* count);
 
 /* intersect_bvh(bvh, scene, ray) (instance < 0) / intersect_bvh(bvh, scene, instance, ray) of yocto_bvh.h, for a

@@ -9,6 +9,8 @@
 #include <cstring>
 #include <algorithm>
 #include <limits>
+#include <queue>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -239,6 +241,15 @@ struct vpt_scene {
 
   void*     sort_temp = nullptr;
   size_t    sort_temp_bytes = 0;
+  // tile splitting (launch_mesh): tiles whose pixels run as 2^k partly filled waves, so that a launch is not as long as its costliest tile
+  int*      d_lane_slot = nullptr;
+  long long lane_cap = 0;
+  int       split_waves = 0, split_tiles = 0;   // waves of the split launch (0: no table), tiles that were split
+  std::vector<int> h_split_k;                   // per tile: it runs as 2^k waves
+  bool      full_costs = false;                 // d_cost holds per-tile durations of a full unsplit launch
+  int       wave_slots_k1 = 3072;               // wave slots of the chip for K1 (CUs x 4 SIMDs x 3)
+  bool      split_decided = false;              // the decision for sched_key has been taken (costs of an unsplit launch were available)
+  int       last_waves = 0;                     // grid of the last kernel launch (vpt_last_wave_costs)
   long long sched_waves = 0;       // waves the buffers are sized for
   bool      order_valid = false;   // d_order describes the layout of sched_key
   long long sched_key[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -434,7 +445,7 @@ void vpt_scene_destroy(vpt_scene* s) {
     if (p) (void)hipFree(p);
   for (void* p : s->path_allocs) (void)hipFree(p);
   if (s->spill) (void)hipFree(s->spill);
-  for (void* p : {(void*)s->d_cost, (void*)s->d_cost_sorted, (void*)s->d_order, (void*)s->d_iota, s->sort_temp})
+  for (void* p : {(void*)s->d_cost, (void*)s->d_cost_sorted, (void*)s->d_order, (void*)s->d_iota, s->sort_temp, (void*)s->d_lane_slot})
     if (p) (void)hipFree(p);
   if (s->ev_order) (void)hipEventDestroy(s->ev_order);
   if (s->host_counts) (void)hipHostFree(s->host_counts);
@@ -830,6 +841,7 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
     if (per_cu > 4) per_cu = 4;   // __launch_bounds__(256, 4): 4 waves/SIMD = 4 workgroups/CU
     if (per_cu < 1) per_cu = 1;
     s->trace_blocks = prop.multiProcessorCount * per_cu;
+    s->wave_slots_k1 = prop.multiProcessorCount * 4 * VPT_WAVES_PER_SIMD;
   }
   if (d.num_lights > 0) {   // element normals of the single-leaf mesh lights, by the device's own eval_element_normal
     hipLaunchKernelGGL(vpt_light_setup_kernel, dim3(d.num_lights), dim3(64), 0, 0, s->d, const_cast<float4*>(D.light_prims));
@@ -985,7 +997,8 @@ static int sched_prepare(vpt_scene* s, long long waves, const long long key[10],
     HIP_TRY(hipMalloc(&s->sort_temp, bytes ? bytes : 16));
     s->sort_temp_bytes = bytes, s->sched_waves = waves;
   }
-  if (memcmp(key, s->sched_key, sizeof(s->sched_key)) != 0) s->order_valid = false, memcpy(s->sched_key, key, sizeof(s->sched_key));
+  if (memcmp(key, s->sched_key, sizeof(s->sched_key)) != 0)
+    s->order_valid = false, s->split_decided = false, s->full_costs = false, s->split_waves = 0, s->split_tiles = 0, memcpy(s->sched_key, key, sizeof(s->sched_key));
   (void)st;
   return VPT_OK;
 }
@@ -1063,6 +1076,115 @@ static void schedule_key(const launch_ctx& L, long long key[10]) {
   memcpy(key, k, sizeof(k));
 }
 
+// ---- tile splitting (K1) --------------------------------------------------------------------------------------------
+// A wave runs all samples of its 64 pixels one after the other, so a launch cannot be shorter than its costliest tile.
+// On one GPU that tile (273 ms of a 280 ms launch on 03_volume) is level with total work / wave slots and nothing is
+// gained by shortening it; once the frame is shared among N GPUs the work per GPU falls with N and the chain does not.
+// A tile can be run as 2^k waves that hold every 2^k-th pixel in their first 64 >> k lanes: fewer live lanes diverge
+// less, the wave's trips get faster (g[k] below, measured on MI355X: DESIGN.md §5) - at 2^k g[k] times the slot time.
+// Policy: the smallest span S such that, with every tile split just enough to fit (cost g[k] <= S), the slot time of all
+// waves still fits in S with the usual tail (7 %).  Taken once per layout / shader / camera from the per-tile costs of an
+// unsplit launch; pixels keep their own RNG streams and accumulators, so the result does not depend on it.
+static const double split_gain[7] = {1.0, 0.81, 0.62, 0.45, 0.35, 0.27, 0.20};   // duration of a 64 >> k lane wave of a costly tile / its full wave
+static int split_mode() {   // VPT_SPLIT: 0 never, 1 always consider, unset: consider when the frame is shared among ranks
+  static int v = [] { const char* e = getenv("VPT_SPLIT"); return e ? atoi(e) : -1; }();
+  return v;
+}
+static int split_forced_k() {   // VPT_SPLIT_K (calibration): every tile as 2^k waves
+  static int v = [] { const char* e = getenv("VPT_SPLIT_K"); return e ? atoi(e) : -1; }();
+  return v;
+}
+// lane table and predicted wave costs for the split factors s->h_split_k; part_cost[t] = expected duration of one wave of tile t
+static int build_split_table(vpt_scene* s, const DParams& pr, const std::vector<double>& part_cost, hipStream_t st) {
+  const std::vector<int>& k = s->h_split_k;
+  const int ntiles = (int)k.size();
+  long long waves = 0;
+  int       nsplit = 0;
+  for (int t = 0; t < ntiles; t++) waves += 1ll << k[t], nsplit += k[t] > 0;
+  s->split_waves = 0, s->split_tiles = 0;
+  if (nsplit == 0 || waves > (1ll << 24)) return VPT_OK;
+  std::vector<int>      table((size_t)waves * VPT_BLOCK, -1);
+  std::vector<unsigned> wcost((size_t)waves);
+  long long w = 0;
+  for (int t = 0; t < ntiles; t++)
+    for (int part = 0; part < (1 << k[t]); part++, w++) {
+      wcost[(size_t)w] = (unsigned)part_cost[t];
+      for (int lane = 0; lane < (VPT_BLOCK >> k[t]); lane++) table[(size_t)w * VPT_BLOCK + lane] = t * VPT_BLOCK + (lane << k[t]) + part;
+    }
+  if ((long long)table.size() > s->lane_cap) {
+    if (s->d_lane_slot) (void)hipFree(s->d_lane_slot), s->d_lane_slot = nullptr;
+    s->lane_cap = 0;
+    HIP_TRY(hipMalloc((void**)&s->d_lane_slot, table.size() * 4));
+    s->lane_cap = (long long)table.size();
+  }
+  long long key[10];
+  memcpy(key, s->sched_key, sizeof(key));
+  if (int rc = sched_prepare(s, waves, key, st)) return rc;   // may reallocate d_cost / d_order for the larger wave count
+  HIP_TRY(hipMemcpy(s->d_lane_slot, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->d_cost, wcost.data(), wcost.size() * 4, hipMemcpyHostToDevice));
+  s->split_waves = (int)waves, s->split_tiles = nsplit;
+  if (getenv("VPT_SPLIT_VERBOSE"))
+    fprintf(stderr, "[vpt] split: %d of %d tiles -> %lld waves on %d slots (rank %d of %d)\n", nsplit, ntiles, waves, s->wave_slots_k1, pr.rank, pr.nranks);
+  return sched_update(s, waves, st);   // order of the split launch from the predicted costs; measured ones take over afterwards
+}
+// makespan of longest-first list scheduling of `costs` (any order) on `slots` machines: what the hardware's dispatch of
+// the launch in d_order amounts to
+static double lpt_makespan(std::vector<double>& costs, int slots) {
+  std::sort(costs.begin(), costs.end(), std::greater<double>());
+  std::priority_queue<double, std::vector<double>, std::greater<double>> load;
+  double span = 0;
+  for (size_t i = 0; i < costs.size(); i++) {
+    double at = 0;
+    if ((int)load.size() >= slots) at = load.top(), load.pop();
+    load.push(at + costs[i]);
+    span = std::max(span, at + costs[i]);
+  }
+  return span;
+}
+// A wave also runs faster when fewer waves share its SIMD: the costliest tile of 03_volume takes 273 ms with all 3 072
+// slots busy and 187 ms when 1 340 waves are resident: duration ~ (0.46 + 0.54 * occupancy) * duration at 1
+static double load_factor(double waves, int slots) { return 0.46 + 0.54 * std::min(1.0, waves / slots); }
+static int decide_split(vpt_scene* s, const DParams& pr, int ntiles, int slots, hipStream_t st) {
+  s->split_decided = true, s->split_waves = 0, s->split_tiles = 0;
+  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<unsigned> cost((size_t)ntiles);
+  HIP_TRY(hipMemcpy(cost.data(), s->d_cost, cost.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<int>& k = s->h_split_k;
+  k.assign((size_t)ntiles, 0);
+  double cmax = 0;
+  int    live = 0;
+  for (unsigned c : cost) cmax = std::max(cmax, (double)c), live += c > 0;
+  if (cmax <= 0) return VPT_OK;
+  const double measured_at = load_factor(live, slots);   // the costs were measured with `live` waves resident
+  std::vector<double> waves;
+  auto plan = [&](double S, bool apply) {   // predicted span when every tile is split just enough for its waves to fit S
+    waves.clear();
+    for (int t = 0; t < ntiles; t++) {
+      if (cost[t] == 0) continue;
+      int kt = 0;
+      while (kt < 6 && cost[t] * split_gain[kt] > S) kt++;
+      if (apply) k[t] = kt;
+      for (int p = 0; p < (1 << kt); p++) waves.push_back(cost[t] * split_gain[kt]);
+    }
+    double f = load_factor((double)waves.size(), slots) / measured_at;
+    for (double& w : waves) w *= f;
+    return lpt_makespan(waves, slots);
+  };
+  if (split_forced_k() >= 0) {
+    for (int t = 0; t < ntiles; t++) k[t] = std::min(split_forced_k(), 6);
+  } else {
+    double best_S = cmax, best = plan(cmax, false);
+    for (int i = 1; i <= 24; i++) {   // candidates from the costliest tile down to its 1-lane duration
+      double S = cmax * std::pow(split_gain[6], i / 24.0), span = plan(S, false);
+      if (span < best * 0.98) best = span, best_S = S;   // a split has to pay at least 2 %
+    }
+    plan(best_S, true);
+  }
+  std::vector<double> part((size_t)ntiles);
+  for (int t = 0; t < ntiles; t++) part[t] = cost[t] * split_gain[k[t]];
+  return build_split_table(s, pr, part, st);
+}
+
 // K1 (mesh shaders).  Longest-wave-first order from the costs of the previous launch on this layout; without
 // them a pilot launch over 1/64 of the call's samples (1..16) measures them first - same arithmetic, batching is exact.
 template <int K>
@@ -1071,22 +1193,29 @@ static int launch_mesh(const launch_ctx& L) {
   if (use_stream_pipeline()) return render_stream<K>(s, L.pr, L.img, L.hit, L.rng, L.st);
   long long key[10];
   schedule_key(L, key);
-  if (int rc = sched_prepare(s, L.grid.x, key, L.st)) return rc;
+  if (int rc = sched_prepare(s, std::max<long long>(L.grid.x, s->split_waves), key, L.st)) return rc;
   if (int rc = sched_wait(s, L.st)) return rc;
   size_t lds = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int);   // (ref, t0) pairs
   int n = L.pr.nsamples, pilot = n / 64 < 1 ? 1 : n / 64 > 16 ? 16 : n / 64;
   int parts[2] = {(!s->order_valid && n >= 16) ? pilot : n, 0};
   parts[1] = n - parts[0];
+  const bool may_split = !L.stack.spill && (split_mode() == 1 || split_forced_k() >= 0 || (split_mode() < 0 && L.pr.nranks > 1));
   for (int part = 0; part < 2 && parts[part] > 0; part++) {
     DParams pr  = L.pr;
     pr.nsamples = parts[part];
-    sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost};
     bool is_pilot = parts[1] > 0 && part == 0;
-    if (is_pilot && L.stack.spill) hipLaunchKernelGGL((vpt_mesh_pilot_kernel<K, true>), L.grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
-    else if (is_pilot) hipLaunchKernelGGL((vpt_mesh_pilot_kernel<K, false>), L.grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
-    else if (L.stack.spill) hipLaunchKernelGGL((vpt_mesh_kernel<K, true>), L.grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
-    else hipLaunchKernelGGL((vpt_mesh_kernel<K, false>), L.grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
-    if (int rc = sched_update(s, L.grid.x, L.st)) return rc;
+    // the costs of a full unsplit launch (not of the few-sample pilot) decide, once, whether tiles are split from now on
+    if (may_split && !s->split_decided && s->order_valid && s->full_costs)
+      if (int rc = decide_split(s, pr, (int)L.grid.x, s->wave_slots_k1, L.st)) return rc;
+    dim3 grid = s->split_waves > 0 ? dim3((unsigned)s->split_waves) : L.grid;
+    sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, s->split_waves > 0 ? s->d_lane_slot : nullptr};
+    if (is_pilot && L.stack.spill) hipLaunchKernelGGL((vpt_mesh_pilot_kernel<K, true>), grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
+    else if (is_pilot) hipLaunchKernelGGL((vpt_mesh_pilot_kernel<K, false>), grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
+    else if (L.stack.spill) hipLaunchKernelGGL((vpt_mesh_kernel<K, true>), grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
+    else hipLaunchKernelGGL((vpt_mesh_kernel<K, false>), grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
+    if (s->split_waves == 0) s->full_costs = !is_pilot && pr.nsamples >= 8;   // d_cost now holds per-tile durations of a real launch
+    s->last_waves = (int)grid.x;
+    if (int rc = sched_update(s, grid.x, L.st)) return rc;
   }
   return VPT_OK;
 }
@@ -1101,7 +1230,8 @@ static int launch_implicit(const launch_ctx& L) {
   size_t    lds = (size_t)s->stack_cap * VPT_BLOCK * sizeof(int) +                                      // refs-only stack
                (6 * (size_t)s->d.num_sdfs + 7 * (size_t)s->d.num_vol_instances) * sizeof(float4);       // the SDF records
   if (lds > 64 * 1024) return fail(VPT_ERR_UNSUPPORTED, "scene has too many SDFs for the implicit kernel's LDS copy of their records (%d + %d)", s->d.num_sdfs, s->d.num_vol_instances);
-  sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost};
+  sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, nullptr};
+  s->last_waves = (int)L.grid.x;
   hipLaunchKernelGGL(vpt_render_kernel<K>, L.grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog);
   return sched_update(s, L.grid.x, L.st);
 }
@@ -1152,7 +1282,7 @@ int vpt_last_wave_costs(vpt_scene* s, unsigned* ticks, int capacity, int* count)
   if (!s->timed) return fail(VPT_ERR_INVALID_ARG, "no launch recorded");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipEventSynchronize(s->ev1));
-  long long n = s->sched_key[0] / VPT_BLOCK;   // waves of the last launch's layout (sched_key[0] = its state slots)
+  long long n = s->last_waves;   // waves of the last launch
   *count = (int)n;
   if (n > capacity) n = capacity;
   if (n > 0) HIP_TRY(hipMemcpy(ticks, s->d_cost, (size_t)n * 4, hipMemcpyDeviceToHost));

@@ -38,8 +38,10 @@ VPT_DEV bool survive(f3& weight, int bounce, rng_t& rng) {
 // waves longest first (order[] = wave indices by descending cost: LPT list scheduling).  Results do not depend
 // on the order (pixels are independent), only the makespan does.
 struct sched_cfg {
-  const int* order;   // blockIdx.x -> wave index, or null: identity
-  unsigned*  cost;    // per wave: duration of this launch in 100 MHz ticks, or null
+  const int* order;       // blockIdx.x -> wave index, or null: identity
+  unsigned*  cost;        // per wave: duration of this launch in 100 MHz ticks, or null
+  const int* lane_slot;   // [wave][64] -> state slot of the lane (-1: none), or null: slot = wave * 64 + lane (one tile per wave).
+                          // Set when costly tiles run as several partly filled waves (vpt_capi.hip: tile splitting)
 };
 // ---- state layout conversion and output resolve ---------------------------------------------
 // row-major host-order arrays <-> this rank's tile-major slots (vpt_state_upload / _download)

@@ -507,8 +507,9 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
 #endif
 
   int slot = wave * VPT_BLOCK + threadIdx.x;
+  if (sched.lane_slot) slot = sched.lane_slot[slot];   // a split tile: this wave holds every 2^k-th pixel of it in its first lanes
   int px = 0, py = 0;
-  if (slot >= pr.nslots || !slot_to_pixel(pr, slot, px, py)) return;   // padding lanes own no pixel
+  if (slot < 0 || slot >= pr.nslots || !slot_to_pixel(pr, slot, px, py)) return;   // padding lanes own no pixel
 
   float4     acc_in = image[slot];
   f4         acc    = mk4(acc_in.x, acc_in.y, acc_in.z, acc_in.w);

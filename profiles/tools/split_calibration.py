@@ -29,7 +29,7 @@ hit = torch.zeros((slots,), dtype=torch.int32, device=d)
 rng = torch.zeros((slots, 2), dtype=torch.int64, device=d)
 vpt.state_upload(lay, host, img.data_ptr(), hit.data_ptr(), rng.data_ptr())
 ms = []
-for _ in range(7):
+for _ in range(8):
     dev.render_device(p, lay, spp, img.data_ptr(), hit.data_ptr(), rng.data_ptr(), 0)
     torch.cuda.synchronize()
     ms.append(dev.last_kernel_ms())

@@ -314,10 +314,11 @@ int vpt_last_kernel_ms(vpt_scene* scene, float* ms);
  *
  * Tile splitting.  A wave runs all samples of its pixels one after the other, so a launch is at least as long as its
  * costliest tile.  When a layout shares the frame among ranks (nranks > 1) the work per GPU falls with N and that
- * chain does not: from the second full call on a layout, the mesh kernels then run the costliest tiles as 2^k waves
+ * chain does not, and a small frame (fewer than three tiles per wave slot of the chip) is in the same position: from the
+ * second full call on such a layout the mesh kernels run the costliest tiles as 2^k waves
  * that hold every 2^k-th pixel (fewer live lanes diverge less: a wave with 8 lanes takes ~0.45 of the time), chosen
  * once from the measured per-tile costs by simulating the launch's schedule.  Results do not depend on it (pixels own
- * their RNG streams).  VPT_SPLIT=0 disables it, VPT_SPLIT=1 also considers it for nranks == 1 (never pays there). */
+ * their RNG streams).  VPT_SPLIT=0 disables it, VPT_SPLIT=1 considers it for every layout (it never pays on a full-size frame on one GPU). */
 int vpt_last_wave_costs(vpt_scene* scene, unsigned* ticks, int capacity, int* count);
 
 /* intersect_bvh(bvh, scene, ray) (instance < 0) / intersect_bvh(bvh, scene, instance, ray) of yocto_bvh.h, for a

@@ -1,7 +1,7 @@
 """Tile splitting (include/vpt.h, vpt_capi.hip): when a layout shares the frame among ranks, the mesh kernels run the
 costliest tiles as several partly filled waves so that a launch is not as long as its costliest tile.  It is a change of
 schedule only: every pixel keeps its own RNG stream and accumulator, so the state must be bit-identical with and without
-it - checked here on one GPU with virtual ranks, across the call in which the decision is taken (call 1: pilot + unsplit
+it - checked here on one GPU with virtual ranks and with small frames, across the call in which the decision is taken (call 1: pilot + unsplit
 launch that measures the tiles; call 2: decision, first split launch; call 3: split launch in measured order)."""
 import os
 import subprocess
@@ -55,6 +55,18 @@ def test_adaptive_split_of_a_shared_frame_gives_the_same_state(tmp_path):
     assert auto["ms"][2] < 0.85 * base["ms"][2]     # measured on MI355X: ~0.6
 
 
-def test_a_whole_frame_on_one_gpu_is_left_alone(tmp_path):
-    one = _run(tmp_path, "one", {}, 640, 1, 0, 32, 3)
+def test_a_full_size_frame_on_one_gpu_is_left_alone(tmp_path):
+    """1280x533 = 10 720 tiles on 3 072 wave slots: the launch is bound by total work, the policy is not even consulted"""
+    one = _run(tmp_path, "one", {}, 1280, 1, 0, 16, 3)
     assert list(one["waves"]) == [int(one["tiles"])] * 3
+
+
+def test_a_small_frame_on_one_gpu_is_split_and_unchanged(tmp_path):
+    """the reference's default resolution (720x300, 3 420 tiles) leaves most wave slots idle behind its costliest tiles"""
+    base = _run(tmp_path, "base", {"VPT_SPLIT": "0"}, 720, 1, 0, 32, 3)
+    auto = _run(tmp_path, "auto", {}, 720, 1, 0, 32, 3)
+    tiles = int(base["tiles"])
+    assert list(base["waves"]) == [tiles] * 3 and auto["waves"][0] == tiles and auto["waves"][2] > tiles
+    assert _same_state(base, auto)
+    print("720x300x32spp on one GPU: unsplit", base["ms"], "ms; split", auto["ms"], "ms")
+    assert auto["ms"][2] < 0.9 * base["ms"][2]     # measured on MI355X at 256 spp: 212 -> 152 ms

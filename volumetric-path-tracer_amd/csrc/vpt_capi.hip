@@ -1082,11 +1082,14 @@ static void schedule_key(const launch_ctx& L, long long key[10]) {
 // gained by shortening it; once the frame is shared among N GPUs the work per GPU falls with N and the chain does not.
 // A tile can be run as 2^k waves that hold every 2^k-th pixel in their first 64 >> k lanes: fewer live lanes diverge
 // less, the wave's trips get faster (g[k] below, measured on MI355X: DESIGN.md §5) - at 2^k g[k] times the slot time.
-// Policy: the smallest span S such that, with every tile split just enough to fit (cost g[k] <= S), the slot time of all
-// waves still fits in S with the usual tail (7 %).  Taken once per layout / shader / camera from the per-tile costs of an
-// unsplit launch; pixels keep their own RNG streams and accumulators, so the result does not depend on it.
+// Policy (decide_split): for a range of candidate spans S every tile is split just enough for its waves to fit S and the
+// resulting launch is simulated (longest-first list scheduling on the chip's wave slots, durations scaled by how full the
+// chip is); the shortest simulated launch wins if it beats the unsplit one by 2 %.  Taken once per layout / shader /
+// camera from the per-tile costs of an unsplit launch, when the launch is short of waves: the frame is shared among ranks
+// or holds fewer than three tiles per wave slot (1280x533 on one MI355X has 3.5 and never gains).  Pixels keep their own RNG streams and accumulators, so the result does
+// not depend on it.
 static const double split_gain[7] = {1.0, 0.81, 0.62, 0.45, 0.35, 0.27, 0.20};   // duration of a 64 >> k lane wave of a costly tile / its full wave
-static int split_mode() {   // VPT_SPLIT: 0 never, 1 always consider, unset: consider when the frame is shared among ranks
+static int split_mode() {   // VPT_SPLIT: 0 never, 1 always consider, unset: consider when the launch is short of waves
   static int v = [] { const char* e = getenv("VPT_SPLIT"); return e ? atoi(e) : -1; }();
   return v;
 }
@@ -1199,7 +1202,8 @@ static int launch_mesh(const launch_ctx& L) {
   int n = L.pr.nsamples, pilot = n / 64 < 1 ? 1 : n / 64 > 16 ? 16 : n / 64;
   int parts[2] = {(!s->order_valid && n >= 16) ? pilot : n, 0};
   parts[1] = n - parts[0];
-  const bool may_split = !L.stack.spill && (split_mode() == 1 || split_forced_k() >= 0 || (split_mode() < 0 && L.pr.nranks > 1));
+  const bool may_split = !L.stack.spill && (split_mode() == 1 || split_forced_k() >= 0 ||
+                                            (split_mode() < 0 && (L.pr.nranks > 1 || (long long)L.grid.x < 3ll * s->wave_slots_k1)));
   for (int part = 0; part < 2 && parts[part] > 0; part++) {
     DParams pr  = L.pr;
     pr.nsamples = parts[part];

@@ -246,7 +246,7 @@ struct vpt_scene {
   long long lane_cap = 0;
   int       split_waves = 0, split_tiles = 0;   // waves of the split launch (0: no table), tiles that were split
   std::vector<int> h_split_k;                   // per tile: it runs as 2^k waves
-  bool      full_costs = false;                 // d_cost holds per-tile durations of a full unsplit launch
+  bool      full_costs = false;                 // d_cost holds per-tile durations of an unsplit launch over >= 8 samples
   int       wave_slots_k1 = 3072;               // wave slots of the chip for K1 (CUs x 4 SIMDs x 3)
   bool      split_decided = false;              // the decision for sched_key has been taken (costs of an unsplit launch were available)
   int       last_waves = 0;                     // grid of the last kernel launch (vpt_last_wave_costs)
@@ -1208,7 +1208,7 @@ static int launch_mesh(const launch_ctx& L) {
     DParams pr  = L.pr;
     pr.nsamples = parts[part];
     bool is_pilot = parts[1] > 0 && part == 0;
-    // the costs of a full unsplit launch (not of the few-sample pilot) decide, once, whether tiles are split from now on
+    // the costs of an unsplit launch over at least 8 samples decide, once, whether tiles are split from now on
     if (may_split && !s->split_decided && s->order_valid && s->full_costs)
       if (int rc = decide_split(s, pr, (int)L.grid.x, s->wave_slots_k1, L.st)) return rc;
     dim3 grid = s->split_waves > 0 ? dim3((unsigned)s->split_waves) : L.grid;
@@ -1217,7 +1217,7 @@ static int launch_mesh(const launch_ctx& L) {
     else if (is_pilot) hipLaunchKernelGGL((vpt_mesh_pilot_kernel<K, false>), grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
     else if (L.stack.spill) hipLaunchKernelGGL((vpt_mesh_kernel<K, true>), grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
     else hipLaunchKernelGGL((vpt_mesh_kernel<K, false>), grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
-    if (s->split_waves == 0) s->full_costs = !is_pilot && pr.nsamples >= 8;   // d_cost now holds per-tile durations of a real launch
+    if (s->split_waves == 0) s->full_costs = pr.nsamples >= 8;   // d_cost now holds per-tile durations over enough samples (a pilot of a call with >= 512 samples counts)
     s->last_waves = (int)grid.x;
     if (int rc = sched_update(s, grid.x, L.st)) return rc;
   }

@@ -1088,7 +1088,21 @@ static void schedule_key(const launch_ctx& L, long long key[10]) {
 // camera from the per-tile costs of an unsplit launch, when the launch is short of waves: the frame is shared among ranks
 // or holds fewer than three tiles per wave slot (1280x533 on one MI355X has 3.5 and never gains).  Pixels keep their own RNG streams and accumulators, so the result does
 // not depend on it.
-static const double split_gain[7] = {1.0, 0.81, 0.62, 0.45, 0.35, 0.27, 0.20};   // duration of a 64 >> k lane wave of a costly tile / its full wave
+static double split_gain[7] = {1.0, 0.81, 0.62, 0.45, 0.35, 0.27, 0.20};   // duration of a 64 >> k lane wave of a costly tile / its full wave
+static double split_load0 = 0.46, split_margin = 0.98;   // load_factor's intercept; a split has to beat the unsplit launch by this factor
+static void split_tuning() {   // VPT_SPLIT_TUNE="g1,g2,g3,g4,g5,g6,load0,margin" (calibration runs only)
+  static bool once = [] {
+    if (const char* e = getenv("VPT_SPLIT_TUNE")) {
+      double v[8];
+      if (sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7) == 8) {
+        for (int i = 0; i < 6; i++) split_gain[i + 1] = v[i];
+        split_load0 = v[6], split_margin = v[7];
+      }
+    }
+    return true;
+  }();
+  (void)once;
+}
 static int split_mode() {   // VPT_SPLIT: 0 never, 1 always consider, unset: consider when the launch is short of waves
   static int v = [] { const char* e = getenv("VPT_SPLIT"); return e ? atoi(e) : -1; }();
   return v;
@@ -1146,9 +1160,10 @@ static double lpt_makespan(std::vector<double>& costs, int slots) {
 }
 // A wave also runs faster when fewer waves share its SIMD: the costliest tile of 03_volume takes 273 ms with all 3 072
 // slots busy and 187 ms when 1 340 waves are resident: duration ~ (0.46 + 0.54 * occupancy) * duration at 1
-static double load_factor(double waves, int slots) { return 0.46 + 0.54 * std::min(1.0, waves / slots); }
+static double load_factor(double waves, int slots) { return split_load0 + (1 - split_load0) * std::min(1.0, waves / slots); }
 static int decide_split(vpt_scene* s, const DParams& pr, int ntiles, int slots, hipStream_t st) {
   s->split_decided = true, s->split_waves = 0, s->split_tiles = 0;
+  split_tuning();
   HIP_TRY(hipStreamSynchronize(st));
   std::vector<unsigned> cost((size_t)ntiles);
   HIP_TRY(hipMemcpy(cost.data(), s->d_cost, cost.size() * 4, hipMemcpyDeviceToHost));
@@ -1179,7 +1194,7 @@ static int decide_split(vpt_scene* s, const DParams& pr, int ntiles, int slots, 
     double best_S = cmax, best = plan(cmax, false);
     for (int i = 1; i <= 24; i++) {   // candidates from the costliest tile down to its 1-lane duration
       double S = cmax * std::pow(split_gain[6], i / 24.0), span = plan(S, false);
-      if (span < best * 0.98) best = span, best_S = S;   // a split has to pay at least 2 %
+      if (span < best * split_margin) best = span, best_S = S;   // a split has to pay at least 2 %
     }
     plan(best_S, true);
   }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Tile splitting (vpt_capi.hip): one virtual rank of an N-GPU job on this GPU.
-  split_calibration.py <nranks> <spp> [rank]   -> kernel ms, longest wave, slot time of the steady-state launch, state hash
+  split_calibration.py <nranks> <spp> [rank [scene file [shader [bounces [resolution]]]]]   -> kernel ms, longest wave, slot time of the steady-state launch, state hash
 Environment: VPT_SPLIT (0 / 1), VPT_SPLIT_K (force every tile to 2^k waves), VPT_SPLIT_VERBOSE."""
 import hashlib
 import os
@@ -17,9 +17,13 @@ import vpt_loader
 vpt = vpt_loader.load()
 nranks, spp = int(sys.argv[1]), int(sys.argv[2])
 rank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-scene = vpt.HostScene(os.path.join(ROOT, "tests", "golden", "scenes", "03_volume", "volume.json"))
+scene_file = sys.argv[4] if len(sys.argv) > 4 else "03_volume/volume.json"
+shader = sys.argv[5] if len(sys.argv) > 5 else "volpathtrace"
+bounces = int(sys.argv[6]) if len(sys.argv) > 6 else 64
+res = int(sys.argv[7]) if len(sys.argv) > 7 else 1280
+scene = vpt.HostScene(os.path.join(ROOT, "tests", "golden", "scenes", scene_file))
 dev = vpt.DeviceScene(scene, 0)
-p = vpt.PathtraceParams(resolution=1280, samples=1 << 20, shader="volpathtrace", bounces=64)
+p = vpt.PathtraceParams(resolution=res, samples=1 << 20, shader=shader, bounces=bounces)
 host = scene.make_state(p)
 lay = vpt.VptLayout(host.width, host.height, 8, 8, rank, nranks)
 slots = vpt.layout_slots(lay)
@@ -29,7 +33,7 @@ hit = torch.zeros((slots,), dtype=torch.int32, device=d)
 rng = torch.zeros((slots, 2), dtype=torch.int64, device=d)
 vpt.state_upload(lay, host, img.data_ptr(), hit.data_ptr(), rng.data_ptr())
 ms = []
-for _ in range(8):
+for _ in range(6):
     dev.render_device(p, lay, spp, img.data_ptr(), hit.data_ptr(), rng.data_ptr(), 0)
     torch.cuda.synchronize()
     ms.append(dev.last_kernel_ms())

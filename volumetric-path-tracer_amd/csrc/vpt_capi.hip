@@ -266,6 +266,7 @@ struct vpt_scene {
   std::vector<void*> path_allocs;
   int*       host_counts = nullptr;   // pinned, 2 ints
   bool       large_mesh_lights = false;
+  int        light_features = 0;      // VPT_FEAT_* bits this scene's lights need from the mesh kernels
   long long  last_iterations = 0;
   int        trace_blocks = 1024;     // resident workgroups of the persistent trace kernel
   // host mirrors of a few index tables: range checks of the batch entry points (vpt_intersect, vpt_kat)
@@ -567,8 +568,8 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   for (int i = 0; i < d.num_lights; i++)
     if (d.lights[i].instance >= 0) {
       int ref = shapes[(size_t)d.instances[d.lights[i].instance].shape].root_ref;
-      if (ref >= 0 || ((~ref) & 15) > 4) s->large_mesh_lights = true;
-    }
+      if (ref >= 0 || ((~ref) & 15) > 4) s->large_mesh_lights = true, s->light_features |= VPT_FEAT_LARGE_LIGHTS;
+    } else if (d.lights[i].sdf >= 0) s->light_features |= VPT_FEAT_SDF_LIGHTS;
   std::vector<DInstance> instances((size_t)d.num_instances);
   for (int i = 0; i < d.num_instances; i++) {
     hframe f = to_h(d.instances[i].frame);
@@ -1228,10 +1229,20 @@ static int launch_mesh(const launch_ctx& L) {
       if (int rc = decide_split(s, pr, (int)L.grid.x, s->wave_slots_k1, L.st)) return rc;
     dim3 grid = s->split_waves > 0 ? dim3((unsigned)s->split_waves) : L.grid;
     sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, s->split_waves > 0 ? s->d_lane_slot : nullptr};
-    if (is_pilot && L.stack.spill) hipLaunchKernelGGL((vpt_mesh_pilot_kernel<K, true>), grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
-    else if (is_pilot) hipLaunchKernelGGL((vpt_mesh_pilot_kernel<K, false>), grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
-    else if (L.stack.spill) hipLaunchKernelGGL((vpt_mesh_kernel<K, true>), grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
-    else hipLaunchKernelGGL((vpt_mesh_kernel<K, false>), grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch);
+    // the instance compiled for the features this scene has (vpt_scene.hip.h: VPT_FEAT_*)
+    const bool lean = s->light_features == 0 && !getenv("VPT_NO_LEAN");
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch); };
+    if (lean) {
+      if (is_pilot && L.stack.spill) launch(vpt_mesh_pilot_kernel<K, true, 0>);
+      else if (is_pilot) launch(vpt_mesh_pilot_kernel<K, false, 0>);
+      else if (L.stack.spill) launch(vpt_mesh_kernel<K, true, 0>);
+      else launch(vpt_mesh_kernel<K, false, 0>);
+    } else {
+      if (is_pilot && L.stack.spill) launch(vpt_mesh_pilot_kernel<K, true, VPT_FEAT_ALL>);
+      else if (is_pilot) launch(vpt_mesh_pilot_kernel<K, false, VPT_FEAT_ALL>);
+      else if (L.stack.spill) launch(vpt_mesh_kernel<K, true, VPT_FEAT_ALL>);
+      else launch(vpt_mesh_kernel<K, false, VPT_FEAT_ALL>);
+    }
     if (s->split_waves == 0) s->full_costs = pr.nsamples >= 8;   // d_cost now holds per-tile durations over enough samples (a pilot of a call with >= 512 samples counts)
     s->last_waves = (int)grid.x;
     if (int rc = sched_update(s, grid.x, L.st)) return rc;

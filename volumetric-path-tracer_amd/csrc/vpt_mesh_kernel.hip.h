@@ -405,11 +405,12 @@ VPT_DEV float small_light_pdf(const DScene& sc, int light_id, float4 r6, float4 
 }
 
 // pdf of the non-mesh lights (environment / sdf), one light: yocto_pathtrace.cpp:381-417
+template <int FEAT = VPT_FEAT_ALL>
 VPT_DEV float other_light_pdf(const DScene& sc, int light_id, int kind, float4 r6, f3 position, f3 direction, int maxiter) {
   if (kind == VPT_LIGHT_ENV_CONST) return 1 / (4 * VPT_PI);
   const vpt_light& light = sc.lights[light_id];
   const float*     cdf   = sc.light_cdf + light.cdf_offset;
-  if (kind == VPT_LIGHT_SDF) {
+  if ((FEAT & VPT_FEAT_SDF_LIGHTS) && kind == VPT_LIGHT_SDF) {
     st_hit h = spheretrace_one(sc, position, direction, light.sdf, maxiter);
     if (!h.hit) return 0;
     f3 lposition = position + direction * h.dist;
@@ -494,7 +495,7 @@ __device__ unsigned long long g_vpt_wave_times[2 * 65536];
 __device__ unsigned g_vpt_wave_hw[65536];   // XCC_ID << 16 | HW_ID[15:0] (wave, simd, pipe, cu, sh, se)
 #endif
 
-template <int SH, bool SPILL>
+template <int SH, bool SPILL, int FEAT>
 VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __restrict__ image, int* __restrict__ hits,
     ulonglong2* __restrict__ rngs, const stack_cfg& stack, const sched_cfg& sched) {
   extern __shared__ int lds_stack[];
@@ -517,6 +518,7 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
   rng_t      rng    = {r_in.x, r_in.y};
   const int  nb     = (SH == K_EYELIGHT) ? max(pr.bounces, 4) : pr.bounces;
   constexpr bool HAS_MIS = (SH == K_VOLPATH || SH == K_PATH);
+  constexpr bool HAS_LARGE = HAS_MIS && (FEAT & VPT_FEAT_LARGE_LIGHTS) != 0;   // else ST_LPDF is never entered
 
   // path state
   ray_t ray      = make_ray(mk3(0, 0, 0), mk3(0, 0, 1));
@@ -561,7 +563,7 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
     } else {
       // ---- the one BVH query of this trip ---------------------------------------------------------
       VPT_CNT(CNT_TRIP);
-      bool  lpdf_query = HAS_MIS && state == ST_LPDF;
+      bool  lpdf_query = HAS_LARGE && state == ST_LPDF;
       int   qinst      = lpdf_query ? sc.lights[lp_light].instance : -1;
       VPT_T0(TM_QUERY);
       hit_t h          = traverse(sc, lpdf_query ? lp_pos : ray.o, ray.d, qinst, stk);
@@ -716,7 +718,7 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
         VPT_T1(TM_VOLUME);
         if constexpr (HAS_MIS) {
           VPT_T0(TM_SAMPLE_LIGHTS);
-          if (want_lights) incoming = sample_lights(sc, position, l_rl, l_rel, l_ruv);
+          if (want_lights) incoming = sample_lights<FEAT>(sc, position, l_rl, l_rel, l_ruv);
           VPT_T1(TM_SAMPLE_LIGHTS);
           VPT_T0(TM_SCATTER_EVAL);
           if (scatter == 1) {   // cpp:626-648
@@ -750,11 +752,11 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
             int    kind = __float_as_int(r7.w) & 255;
             if (kind == VPT_LIGHT_SMALL_MESH) {   // single-leaf shape: inline walk
               lp_sum += small_light_pdf(sc, lp_light, r6, r7, ray.o, ray.d);
-            } else if (kind == VPT_LIGHT_LARGE_MESH) {   // needs real BVH hops: hand over to the traversal (extra trips)
+            } else if (HAS_LARGE && kind == VPT_LIGHT_LARGE_MESH) {   // needs real BVH hops: hand over to the traversal (extra trips)
               lp_cur = 0, lp_hop = 0, lp_pos = ray.o, state = ST_LPDF;
               break;
             } else {
-              lp_sum += other_light_pdf(sc, lp_light, kind, r6, ray.o, ray.d, pr.spheretrace_maxiter);
+              lp_sum += other_light_pdf<FEAT>(sc, lp_light, kind, r6, ray.o, ray.d, pr.spheretrace_maxiter);
             }
             lp_light++;
           }
@@ -805,15 +807,15 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
   }
 }
 
-template <int SH, bool SPILL>
+template <int SH, bool SPILL, int FEAT>
 __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_kernel(DScene sc, DParams pr,
     float4* __restrict__ image, int* __restrict__ hits, ulonglong2* __restrict__ rngs, stack_cfg stack, sched_cfg sched) {
-  mesh_kernel_body<SH, SPILL>(sc, pr, image, hits, rngs, stack, sched);
+  mesh_kernel_body<SH, SPILL, FEAT>(sc, pr, image, hits, rngs, stack, sched);
 }
 // The same kernel under another name: the one-sample launch that measures per-wave costs when none are
 // known yet (vpt_capi.hip).  Kept apart so that profiles of vpt_mesh_kernel only hold full launches.
-template <int SH, bool SPILL>
+template <int SH, bool SPILL, int FEAT>
 __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_mesh_pilot_kernel(DScene sc, DParams pr,
     float4* __restrict__ image, int* __restrict__ hits, ulonglong2* __restrict__ rngs, stack_cfg stack, sched_cfg sched) {
-  mesh_kernel_body<SH, SPILL>(sc, pr, image, hits, rngs, stack, sched);
+  mesh_kernel_body<SH, SPILL, FEAT>(sc, pr, image, hits, rngs, stack, sched);
 }

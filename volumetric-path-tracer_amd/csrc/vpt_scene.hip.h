@@ -1030,6 +1030,13 @@ VPT_DEV st_hit spheretrace_one(const DScene& sc, f3 ro, f3 rd, int sdf_handle, i
 // ------------------------------------------------------------------------------------------------
 // lights, yocto_pathtrace.cpp:312-421
 // ------------------------------------------------------------------------------------------------
+// Scene features a kernel instance is compiled for (template parameter FEAT of the mesh kernels): code for a feature the
+// scene does not have costs registers in every path (the allocator serves the worst one), so vpt_capi.hip launches the
+// instance without it - 03_volume, whose lights are quads and an environment: 622 -> 676 Msamples/s.
+enum { VPT_FEAT_LARGE_LIGHTS = 1,   // emissive meshes with a real BVH: sample_lights_pdf walks them with extra trips (ST_LPDF)
+       VPT_FEAT_SDF_LIGHTS   = 2,   // SDF lights: a sphere trace inside sample_lights_pdf
+       VPT_FEAT_ALL          = 3 };
+template <int FEAT = VPT_FEAT_ALL>
 VPT_DEV f3 sample_lights(const DScene& sc, f3 position, float rl, float rel, f2 ruv) {
   int           light_id = sample_uniform(sc.num_lights, rl);
   const float4* rec      = sc.light_rec + 8 * (long long)light_id;   // vpt_device.h: everything behind the light id
@@ -1051,11 +1058,11 @@ VPT_DEV f3 sample_lights(const DScene& sc, f3 position, float rl, float rel, f2 
     f3     lp  = tri ? tri_lerp(xyz(c0), xyz(c1), xyz(c2), uv)
                      : (uv.x + uv.y <= 1 ? tri_lerp(xyz(c0), xyz(c1), xyz(c3), uv) : tri_lerp(xyz(c2), xyz(c3), xyz(c1), 1 - uv));
     return normalize(transform_point(unpack_frame(rec[3], rec[4], rec[5]), lp) - position);
-  } else if (kind == VPT_LIGHT_LARGE_MESH) {
+  } else if ((FEAT & VPT_FEAT_LARGE_LIGHTS) && kind == VPT_LIGHT_LARGE_MESH) {
     const DInstance& inst = sc.instances[sc.lights[light_id].instance];
     f2  uv      = sc.shapes[inst.shape].is_triangles ? mk2(1 - sqrtf(ruv.x), ruv.y * sqrtf(ruv.x)) : ruv;
     return normalize(eval_position(sc, inst, pick, uv) - position);
-  } else if (kind == VPT_LIGHT_SDF) {
+  } else if ((FEAT & VPT_FEAT_SDF_LIGHTS) && kind == VPT_LIGHT_SDF) {
     int sdf_id = sc.lights[light_id].sdf;
     const vpt_sdf& sdf = sc.sdfs[sdf_id];
     f3 wlightp  = transform_point(load_frame(sc.sdf_inv + 3 * sdf_id), mk3(ruv.x, ruv.y, 1) * ld3(sdf.whd));

@@ -569,6 +569,7 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
     if (d.lights[i].instance >= 0) {
       int ref = shapes[(size_t)d.instances[d.lights[i].instance].shape].root_ref;
       if (ref >= 0 || ((~ref) & 15) > 4) s->large_mesh_lights = true, s->light_features |= VPT_FEAT_LARGE_LIGHTS;
+      else s->light_features |= VPT_FEAT_SMALL_LIGHTS;
     } else if (d.lights[i].sdf >= 0) s->light_features |= VPT_FEAT_SDF_LIGHTS;
   std::vector<DInstance> instances((size_t)d.num_instances);
   for (int i = 0; i < d.num_instances; i++) {
@@ -1230,13 +1231,13 @@ static int launch_mesh(const launch_ctx& L) {
     dim3 grid = s->split_waves > 0 ? dim3((unsigned)s->split_waves) : L.grid;
     sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, s->split_waves > 0 ? s->d_lane_slot : nullptr};
     // the instance compiled for the features this scene has (vpt_scene.hip.h: VPT_FEAT_*)
-    const bool lean = s->light_features == 0 && !getenv("VPT_NO_LEAN");
+    const bool lean = (s->light_features & (VPT_FEAT_LARGE_LIGHTS | VPT_FEAT_SDF_LIGHTS)) == 0 && !getenv("VPT_NO_LEAN");
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch); };
     if (lean) {
-      if (is_pilot && L.stack.spill) launch(vpt_mesh_pilot_kernel<K, true, 0>);
-      else if (is_pilot) launch(vpt_mesh_pilot_kernel<K, false, 0>);
-      else if (L.stack.spill) launch(vpt_mesh_kernel<K, true, 0>);
-      else launch(vpt_mesh_kernel<K, false, 0>);
+      if (is_pilot && L.stack.spill) launch(vpt_mesh_pilot_kernel<K, true, VPT_FEAT_SMALL_LIGHTS>);
+      else if (is_pilot) launch(vpt_mesh_pilot_kernel<K, false, VPT_FEAT_SMALL_LIGHTS>);
+      else if (L.stack.spill) launch(vpt_mesh_kernel<K, true, VPT_FEAT_SMALL_LIGHTS>);
+      else launch(vpt_mesh_kernel<K, false, VPT_FEAT_SMALL_LIGHTS>);
     } else {
       if (is_pilot && L.stack.spill) launch(vpt_mesh_pilot_kernel<K, true, VPT_FEAT_ALL>);
       else if (is_pilot) launch(vpt_mesh_pilot_kernel<K, false, VPT_FEAT_ALL>);
@@ -1262,7 +1263,11 @@ static int launch_implicit(const launch_ctx& L) {
   if (lds > 64 * 1024) return fail(VPT_ERR_UNSUPPORTED, "scene has too many SDFs for the implicit kernel's LDS copy of their records (%d + %d)", s->d.num_sdfs, s->d.num_vol_instances);
   sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, nullptr};
   s->last_waves = (int)L.grid.x;
-  hipLaunchKernelGGL(vpt_render_kernel<K>, L.grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog);
+  // the instance for the features this scene's lights have (VPT_FEAT_*): SDF scenes without emissive meshes run one without the mesh-light walks
+  if ((s->light_features & (VPT_FEAT_LARGE_LIGHTS | VPT_FEAT_SMALL_LIGHTS)) == 0 && !getenv("VPT_NO_LEAN"))
+    hipLaunchKernelGGL((vpt_render_kernel<K, VPT_FEAT_SDF_LIGHTS>), L.grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog);
+  else
+    hipLaunchKernelGGL((vpt_render_kernel<K, VPT_FEAT_ALL>), L.grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog);
   return sched_update(s, L.grid.x, L.st);
 }
 

@@ -115,10 +115,11 @@ VPT_DEV bool light_march_step(const sdf_recs& recs, int sdf, float area, f3 posi
   return true;
 }
 // the lights of sample_lights_pdf that need no march (mesh lights, environments), one light
+template <int FEAT = VPT_FEAT_ALL>
 VPT_DEV float inline_light_pdf(const DScene& sc, int l, int kind, float4 r6, float4 r7, f3 position, f3 direction, const lane_stack& stk) {
-  if (kind == VPT_LIGHT_SMALL_MESH) return small_light_pdf(sc, l, r6, r7, position, direction);
-  if (kind == VPT_LIGHT_LARGE_MESH) return general_light_pdf(sc, sc.lights[l], position, direction, stk);
-  return other_light_pdf(sc, l, kind, r6, position, direction, 0);   // environments (an SDF light never gets here)
+  if ((FEAT & VPT_FEAT_SMALL_LIGHTS) && kind == VPT_LIGHT_SMALL_MESH) return small_light_pdf(sc, l, r6, r7, position, direction);
+  if ((FEAT & VPT_FEAT_LARGE_LIGHTS) && kind == VPT_LIGHT_LARGE_MESH) return general_light_pdf(sc, sc.lights[l], position, direction, stk);
+  return other_light_pdf<0>(sc, l, kind, r6, position, direction, 0);   // environments (an SDF light never gets here)
 }
 // sample_lights_pdf through the pieces above, start to end for one query: what the kernel does spread over its trips
 // (the known-answer test of K2's code path, vpt_kat_kernels.hip.h)
@@ -137,7 +138,7 @@ VPT_DEV float lights_pdf_k2(const DScene& sc, f3 position, f3 direction, int max
   return sum * ((float)1 / (float)sc.num_lights);
 }
 
-template <int SH>
+template <int SH, int FEAT>
 __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DScene sc, DParams pr, float4* __restrict__ image,
     int* __restrict__ hits, ulonglong2* __restrict__ rngs, int stack_cap, sched_cfg sched, unsigned* __restrict__ watchdog) {
   extern __shared__ int lds_stack[];
@@ -278,7 +279,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
               ruv.y     = rand1f(rng);
               float rel = rand1f(rng);
               float rl  = rand1f(rng);
-              incoming  = sample_lights(sc, position, rl, rel, ruv);
+              incoming  = sample_lights<FEAT>(sc, position, rl, rel, ruv);
             }
             if (is_zero3(incoming)) finish = true;
             else {
@@ -317,7 +318,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
             mode = M_LIGHT;   // needs a march: hand over
             break;
           }
-          lp_sum += inline_light_pdf(sc, lp_light, kind, r6, r7, ro, rd, stk);
+          lp_sum += inline_light_pdf<FEAT>(sc, lp_light, kind, r6, r7, ro, rd, stk);
           lp_light++;
         }
         if (mode == M_LIGHTS) {   // all lights visited: finish the MIS weight (cpp:505-509)

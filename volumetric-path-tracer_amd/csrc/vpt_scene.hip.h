@@ -1035,7 +1035,8 @@ VPT_DEV st_hit spheretrace_one(const DScene& sc, f3 ro, f3 rd, int sdf_handle, i
 // instance without it - 03_volume, whose lights are quads and an environment: 622 -> 676 Msamples/s.
 enum { VPT_FEAT_LARGE_LIGHTS = 1,   // emissive meshes with a real BVH: sample_lights_pdf walks them with extra trips (ST_LPDF)
        VPT_FEAT_SDF_LIGHTS   = 2,   // SDF lights: a sphere trace inside sample_lights_pdf
-       VPT_FEAT_ALL          = 3 };
+       VPT_FEAT_SMALL_LIGHTS = 4,   // emissive meshes of a single BVH leaf (area-light quads): walked inline from their light records
+       VPT_FEAT_ALL          = 7 };
 template <int FEAT = VPT_FEAT_ALL>
 VPT_DEV f3 sample_lights(const DScene& sc, f3 position, float rl, float rel, f2 ruv) {
   int           light_id = sample_uniform(sc.num_lights, rl);
@@ -1046,7 +1047,7 @@ VPT_DEV f3 sample_lights(const DScene& sc, f3 position, float rl, float rel, f2 
   VPT_T0(TM_CDF);
   int pick = (kind == VPT_LIGHT_SMALL_MESH || kind == VPT_LIGHT_LARGE_MESH || kind == VPT_LIGHT_ENV_TEX) ? sample_light_cdf(sc, light_id, rel) : 0;
   VPT_T1(TM_CDF);
-  if (kind == VPT_LIGHT_SMALL_MESH) {
+  if ((FEAT & VPT_FEAT_SMALL_LIGHTS) && kind == VPT_LIGHT_SMALL_MESH) {
     // eval_position (yocto_scene.cpp:279-303) from the light's own copy of its <= 4 primitives
     const float4* prims = sc.light_prims + 20 * (long long)light_id;
     int k = 0;

@@ -86,11 +86,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # VPT_BENCH_REHEARSAL=1: all ranks of an N > 1 job on GPU 0 with gloo (tile buffers staged through the host) - a dry
+    # run of the multi-GPU code path on a one-GPU box; its timings mean nothing and the line says so
+    rehearsal = world > 1 and os.environ.get("VPT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     resolution = int(round(args.resolution * (world ** 0.5))) if args.weak else args.resolution
     scene = vpt.HostScene(args.scene)
@@ -117,7 +125,12 @@ def main():
         done[0] += args.spp
         if record:
             kernel_ms.append(dev.last_kernel_ms())
-        if world > 1:  # tile buffers of all ranks over xGMI, then de-interleave on every rank
+        if rehearsal:
+            torch.cuda.synchronize()
+            parts = [torch.empty((slots, 4), dtype=torch.float32) for _ in range(world)]
+            dist.all_gather(parts, d_image.cpu())
+            gathered.copy_(torch.cat(parts, 0))
+        elif world > 1:  # tile buffers of all ranks over xGMI, then de-interleave on every rank
             dist.all_gather_into_tensor(gathered, d_image)
         vpt.resolve_device(layout, gathered.data_ptr(), done[0], frame.data_ptr(), stream)
 
@@ -142,7 +155,7 @@ def main():
         balance = {"waves": int(len(c)), "longest_wave_ms": round(float(c.max()), 3), "mean_wave_ms": round(float(c.mean()), 4),
                    "sum_wave_ms": round(float(c.sum()), 1), "p99_wave_ms": round(float(np.quantile(c, 0.99)), 3)}
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -252,7 +265,7 @@ def main():
             "metric": "Msamples/sec", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
-            "dtype": "f32", "data": data_desc,
+            "dtype": "f32", "data": data_desc + (" [REHEARSAL: all ranks on one GPU over gloo - timings are not a measurement]" if rehearsal else ""),
             "config": {"workload": f"{scene_name} {args.shader} bounces={args.bounces} {width}x{height}x{args.spp}spp per step" + ("" if world == 1 else (", frame grows with N" if args.weak else ", fixed frame")),
                        "tile": f"{args.tile}x{args.tile}", "parallelism": f"tiles%{world}, costly tiles split into partly filled waves (auto)" if world > 1 else "1gpu",
                        "samples_per_step": samples_per_step},

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <algorithm>
 #include <limits>
+#include <type_traits>
 #include <queue>
 #include <functional>
 #include <string>
@@ -1231,19 +1232,19 @@ static int launch_mesh(const launch_ctx& L) {
     dim3 grid = s->split_waves > 0 ? dim3((unsigned)s->split_waves) : L.grid;
     sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, s->split_waves > 0 ? s->d_lane_slot : nullptr};
     // the instance compiled for the features this scene has (vpt_scene.hip.h: VPT_FEAT_*)
-    const bool lean = (s->light_features & (VPT_FEAT_LARGE_LIGHTS | VPT_FEAT_SDF_LIGHTS)) == 0 && !getenv("VPT_NO_LEAN");
+    const int need = getenv("VPT_NO_LEAN") ? VPT_FEAT_ALL : s->light_features;
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch); };
-    if (lean) {
-      if (is_pilot && L.stack.spill) launch(vpt_mesh_pilot_kernel<K, true, VPT_FEAT_SMALL_LIGHTS>);
-      else if (is_pilot) launch(vpt_mesh_pilot_kernel<K, false, VPT_FEAT_SMALL_LIGHTS>);
-      else if (L.stack.spill) launch(vpt_mesh_kernel<K, true, VPT_FEAT_SMALL_LIGHTS>);
-      else launch(vpt_mesh_kernel<K, false, VPT_FEAT_SMALL_LIGHTS>);
-    } else {
-      if (is_pilot && L.stack.spill) launch(vpt_mesh_pilot_kernel<K, true, VPT_FEAT_ALL>);
-      else if (is_pilot) launch(vpt_mesh_pilot_kernel<K, false, VPT_FEAT_ALL>);
-      else if (L.stack.spill) launch(vpt_mesh_kernel<K, true, VPT_FEAT_ALL>);
-      else launch(vpt_mesh_kernel<K, false, VPT_FEAT_ALL>);
-    }
+    auto launch_feat = [&](auto feat) {
+      constexpr int F = decltype(feat)::value;
+      if (is_pilot && L.stack.spill) launch(vpt_mesh_pilot_kernel<K, true, F>);
+      else if (is_pilot) launch(vpt_mesh_pilot_kernel<K, false, F>);
+      else if (L.stack.spill) launch(vpt_mesh_kernel<K, true, F>);
+      else launch(vpt_mesh_kernel<K, false, F>);
+    };
+    // three instances: single-leaf mesh lights only / + emissive meshes with a BVH / everything (SDF lights too)
+    if ((need & (VPT_FEAT_LARGE_LIGHTS | VPT_FEAT_SDF_LIGHTS)) == 0) launch_feat(std::integral_constant<int, VPT_FEAT_SMALL_LIGHTS>{});
+    else if ((need & VPT_FEAT_SDF_LIGHTS) == 0) launch_feat(std::integral_constant<int, VPT_FEAT_SMALL_LIGHTS | VPT_FEAT_LARGE_LIGHTS>{});
+    else launch_feat(std::integral_constant<int, VPT_FEAT_ALL>{});
     if (s->split_waves == 0) s->full_costs = pr.nsamples >= 8;   // d_cost now holds per-tile durations over enough samples (a pilot of a call with >= 512 samples counts)
     s->last_waves = (int)grid.x;
     if (int rc = sched_update(s, grid.x, L.st)) return rc;

@@ -556,7 +556,9 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   // there).  24 entries per lane = 12 KB per wave keep twelve waves on a CU (144 of 160 KB); whatever the
   // worst case needs beyond that lives in HBM (lane_stack2<true>).
   int need4 = scene_need4 + max_shape_need4 + 1;
-  s->stack_lds4   = need4 < 8 ? 8 : need4 > 24 ? 24 : ((need4 + 3) & ~3);
+  // at most 22 entries in LDS: with the mesh kernel's five parked words per lane (vpt_mesh_kernel.hip.h) a wave then takes
+  // 22 * 512 + 1280 + 8 = 12 552 bytes, just inside ten 1 280-byte granules, and twelve waves fit a CU's 160 KB
+  s->stack_lds4   = need4 < 8 ? 8 : need4 > 22 ? 22 : need4;
   if (const char* e = getenv("VPT_STACK_LDS")) {   // tuning experiments: force a smaller LDS part (the rest spills to HBM)
     int v = atoi(e);
     if (v >= 4 && v < s->stack_lds4) s->stack_lds4 = v;
@@ -1216,7 +1218,7 @@ static int launch_mesh(const launch_ctx& L) {
   schedule_key(L, key);
   if (int rc = sched_prepare(s, std::max<long long>(L.grid.x, s->split_waves), key, L.st)) return rc;
   if (int rc = sched_wait(s, L.st)) return rc;
-  size_t lds = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int);   // (ref, t0) pairs
+  size_t lds = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int) + 5 * VPT_BLOCK * sizeof(float);   // (ref, t0) pairs + the parked words
   int n = L.pr.nsamples, pilot = n / 64 < 1 ? 1 : n / 64 > 16 ? 16 : n / 64;
   int parts[2] = {(!s->order_valid && n >= 16) ? pilot : n, 0};
   parts[1] = n - parts[0];

@@ -509,11 +509,17 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
 
   int slot = wave * VPT_BLOCK + threadIdx.x;
   if (sched.lane_slot) slot = sched.lane_slot[slot];   // a split tile: this wave holds every 2^k-th pixel of it in its first lanes
-  int px = 0, py = 0;
-  if (slot < 0 || slot >= pr.nslots || !slot_to_pixel(pr, slot, px, py)) return;   // padding lanes own no pixel
+  // Cold per-pixel state lives in LDS behind the stacks instead of in registers for the whole launch: the radiance sum
+  // (touched once per sample) and the pixel's coordinates (once per sample) - five words per lane.
+  float* const park = (float*)(lds_stack + stack.cap * 2 * VPT_BLOCK) + threadIdx.x;
+  {
+    int px0 = 0, py0 = 0;
+    if (slot < 0 || slot >= pr.nslots || !slot_to_pixel(pr, slot, px0, py0)) return;   // padding lanes own no pixel
+    park[4 * VPT_BLOCK] = __int_as_float(px0 | (py0 << 16));
+  }
 
   float4     acc_in = image[slot];
-  f4         acc    = mk4(acc_in.x, acc_in.y, acc_in.z, acc_in.w);
+  park[0] = acc_in.x, park[VPT_BLOCK] = acc_in.y, park[2 * VPT_BLOCK] = acc_in.z, park[3 * VPT_BLOCK] = acc_in.w;
   ulonglong2 r_in   = rngs[slot];
   rng_t      rng    = {r_in.x, r_in.y};
   const int  nb     = (SH == K_EYELIGHT) ? max(pr.bounces, 4) : pr.bounces;
@@ -543,8 +549,10 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
       const vpt_camera& cam = sc.cameras[pr.camera];
       float u, v;
       if (pr.preview) {
+        const int pxy = __float_as_int(park[4 * VPT_BLOCK]), px = pxy & 0xffff, py = pxy >> 16;
         u = (px + 0.5f) / pr.width, v = (py + 0.5f) / pr.height;
       } else {
+        const int pxy = __float_as_int(park[4 * VPT_BLOCK]), px = pxy & 0xffff, py = pxy >> 16;
         u = (px + rand1f(rng)) / pr.width;
         v = (py + rand1f(rng)) / pr.height;
       }
@@ -775,7 +783,7 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
     if (finish) {   // cpp:1087-1089
       f4 rad = mk4(radiance.x, radiance.y, radiance.z, alpha);
       if (!(isfinite(rad.x) && isfinite(rad.y) && isfinite(rad.z) && isfinite(rad.w))) rad = mk4(0, 0, 0, 0);
-      acc = acc + rad;
+      park[0] = park[0] + rad.x, park[VPT_BLOCK] = park[VPT_BLOCK] + rad.y, park[2 * VPT_BLOCK] = park[2 * VPT_BLOCK] + rad.z, park[3 * VPT_BLOCK] = park[3 * VPT_BLOCK] + rad.w;
       sample++;
       state = ST_NEW;
     }
@@ -786,14 +794,14 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
   if ((threadIdx.x & 63) == 0)   // lane 0 owns a pixel whenever the wave does (padding lanes sit at the end)
     for (int k = 0; k < 16; k++) atomicAdd(&g_vpt_cnt[32 + k], s_vpt_time[k]);
 #endif
-  image[slot] = make_float4(acc.x, acc.y, acc.z, acc.w);
+  image[slot] = make_float4(park[0], park[VPT_BLOCK], park[2 * VPT_BLOCK], park[3 * VPT_BLOCK]);
   hits[slot] += pr.nsamples;
   ulonglong2 r_out;
   r_out.x = rng.state, r_out.y = rng.inc;
   rngs[slot] = r_out;
   if (sched.cost && threadIdx.x == 0) {   // lane 0 (the tile's corner pixel) exists whenever the wave owns a pixel
     const unsigned long long wave_start = s_wave_start;
-    unsigned long long dt = clock_ticks(__float_as_int(acc.x)) - wave_start;   // after the last sample was accumulated
+    unsigned long long dt = clock_ticks(slot) - wave_start;   // after the last sample was accumulated
     sched.cost[wave] = dt < 0xffffffffull ? (unsigned)dt : 0xffffffffu;
 #ifdef VPT_WAVE_TIMES
     if (wave < 65536) {

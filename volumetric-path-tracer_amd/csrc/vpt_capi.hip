@@ -411,6 +411,7 @@ int validate(const vpt_scene_desc& d) {
 int make_dparams(const vpt_params* p, const vpt_layout* l, int nsamples, DParams& out) {
   REQUIRE(p && l, "null params/layout");
   REQUIRE(l->width > 0 && l->height > 0 && l->nranks > 0 && l->rank >= 0 && l->rank < l->nranks, "bad layout");
+  REQUIRE(l->width < 32768 && l->height < 32768, "frame side must be below 32768 pixels (the kernels keep a pixel's coordinates in one word; the reference's --resolution ends at 4096)");
   REQUIRE(l->tile_w >= 8 && l->tile_h >= 8 && l->tile_w % 8 == 0 && l->tile_h % 8 == 0, "tile size must be a multiple of 8x8");
   out = {};
   out.camera = p->camera, out.shader = p->shader, out.bounces = p->bounces, out.noimplicit_mis = p->noimplicit_mis;

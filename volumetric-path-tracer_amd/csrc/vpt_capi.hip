@@ -557,9 +557,10 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   // there).  24 entries per lane = 12 KB per wave keep twelve waves on a CU (144 of 160 KB); whatever the
   // worst case needs beyond that lives in HBM (lane_stack2<true>).
   int need4 = scene_need4 + max_shape_need4 + 1;
-  // at most 22 entries in LDS: with the mesh kernel's five parked words per lane (vpt_mesh_kernel.hip.h) a wave then takes
-  // 22 * 512 + 1280 + 8 = 12 552 bytes, just inside ten 1 280-byte granules, and twelve waves fit a CU's 160 KB
-  s->stack_lds4   = need4 < 8 ? 8 : need4 > 22 ? 22 : need4;
+  // With the mesh kernel's five parked words per lane (vpt_mesh_kernel.hip.h) a wave takes need4 * 512 + 1280 + 8 bytes of LDS,
+  // granted in 1 280-byte steps: up to 22 entries twelve waves fit a CU's 160 KB, with 23 or 24 eleven do - still better than the
+  // checked push / pop of the HBM-overflow variant (-7 %), which is for deeper trees only (22 entries in LDS, the rest in HBM).
+  s->stack_lds4   = need4 < 8 ? 8 : need4 > 24 ? 22 : need4;
   if (const char* e = getenv("VPT_STACK_LDS")) {   // tuning experiments: force a smaller LDS part (the rest spills to HBM)
     int v = atoi(e);
     if (v >= 4 && v < s->stack_lds4) s->stack_lds4 = v;

@@ -11,24 +11,34 @@ durations the previous launch on the same layout recorded; the v
 process measures them with a short pilot, which therefore falls into the warm-up — the line's `cold` record
 times exactly that first call on a fresh scene handle (N = 1).
 
-N GPUs: the frame is FIXED (1280 wide unless --resolution says otherwise: BASELINE config[4] is --resolution 3840)
-and cut into 8x8-pixel tiles dealt round-robin to the ranks (tile t -> rank t % N); each step ends with an RCCL
-all_gather of the ranks' tile buffers over xGMI and a resolve kernel on every rank.  `scaling` is
-therefore "strong", and after the timed region rank 0 renders the same frame alone (the other ranks wait) so that the
-line carries `speedup_vs_1gpu` measured in the same job.  `--weak` instead grows the frame with N (width x sqrt(N)).
+N GPUs: the frame is FIXED (1280 wide unless --resolution says otherwise) and cut into 8x8-pixel tiles dealt
+round-robin to the ranks (tile t -> rank t % N); each step ends with an RCCL all_gather of the ranks' tile buffers
+over xGMI and a resolve kernel on every rank.  `scaling` is therefore "strong", and after the timed
+region rank 0 renders the same frame alone (the other ranks wait) so that the line carries `speedup_vs_1gpu` measured in
+the same job.  A pixel's samples are a serial chain of RNG draws, so a launch is never shorter than its costliest
+tile: on the 1280x533 headline frame that chain bounds the speed-up to about 2.4x at 8 GPUs, which is why
+the N > 1 line also carries `config5`: BASELINE config[4]'s 3840x1600 frame (9x the tiles, the same chain), timed the
+same way with its own `single_gpu` and `speedup_vs_1gpu` — the frame north_star's ">= 6x at 8 GPUs" is about.
+`--weak` instead grows the frame with N (width x sqrt(N)).  `--dist` runs the N > 1 code path (nccl process group,
+all_gather_into_tensor, resolve of the gathered buffer) at world size 1, so that it executes on a one-GPU box.
 
 The JSON line carries, besides the driver's contract:
-  roofline      algorithmic bytes per launch (SURVEY §8(d) formula, event counts measured by the CPU
-                oracle on a bounded sample of the same workload) / mean kernel time from HIP events
-                on the launch stream, against the 8 TB/s HBM peak.
-  cpu_baseline  the reference's own renderer (oracle/_ref/ref_driver, "reference") or, where that
-                binary is absent, our CPU restatement ("port"), timed on this host's cores on a
-                bounded sample (default 640x267x96 spp, ~10 s) of the same workload.  Rank 0, N=1 only.
+  roofline       algorithmic bytes per launch (SURVEY §8(d) formula, event counts measured by the CPU
+                 oracle on a bounded sample of the same workload) / mean kernel time from HIP events
+                 on the launch stream, against the 8 TB/s HBM peak; `traffic` is the memory-side figure of the
+                 committed rocprofv3 PMC passes named by `traffic_source` (scaled to this launch), not a live counter.
+  cpu_baseline   the reference's own renderer (oracle/_ref/ref_driver, "reference": all hardware threads as the
+                 reference starts them, plus `single_thread`) and our CPU restatement at one thread per core (`port`),
+                 timed on this host's cores on bounded samples of the same workload.  Rank 0, N=1 only.
+  other_configs  (N = 1) the other BASELINE configs' workloads, a few steps each after the timed region: config 3's
+                 substitute scene (05_head1ss_sub volpathtrace), config 4's (06_gridsdf_synth implicit), config 5's frame
+                 (03_volume 3840x1600), each with its own cold first call and roofline record.
 """
 import argparse
 import glob
 import json
 import os
+import re
 import sys
 import time
 
@@ -36,8 +46,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-SCENE = os.path.join(ROOT, "tests", "golden", "scenes", "03_volume", "volume.json")
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
+SCENE = os.path.join(SCENES, "03_volume", "volume.json")
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_ISSUE_PEAK = 1228.8e9   # wave64 VALU instructions / s: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes_per_sample(c):
@@ -52,6 +64,239 @@ def algorithmic_bytes_per_sample(c):
          + 16.0 * c["texel_f32"] + 4.0 * c["texel_u8"] + 4.0 * c["cdf_probes"] + 80.0 * c["surface_hits"]
          + 4.0 * c["voxel_fetches"]) / n + 72.0
     return b
+
+
+def host_cores():
+    """cores this process may actually use (cgroup quota / affinity), not the machine's thread count"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2 CPU quota ("<quota> <period>" or "max <period>")
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def profile_file(tag, kind):
+    """newest profiles/r<round>_<tag>_v<version>_<kind>.json (round 1: r01_v<version>_...), compared numerically"""
+    def version(path):
+        m = re.search(r"r(\d+)_(?:[a-z0-9]+_)?v(\d+)_", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+    files = glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_v*_{kind}.json"))
+    if tag == "k1":
+        files += glob.glob(os.path.join(ROOT, "profiles", f"r01_v*_{kind}.json"))
+    return sorted(files, key=version)[-1] if files else None
+
+
+class Bench:
+    def __init__(self, args):
+        import numpy as np
+        import torch
+        import vpt_loader
+        self.np, self.torch, self.args = np, torch, args
+        self.vpt = vpt_loader.load()
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+            args.gpus = self.world
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        # VPT_BENCH_REHEARSAL=1: all ranks of an N > 1 job on GPU 0 with gloo (tile buffers staged through the host) - a dry
+        # run of the multi-GPU code path on a one-GPU box; its timings mean nothing and the line says so
+        self.rehearsal = self.world > 1 and os.environ.get("VPT_BENCH_REHEARSAL") == "1"
+        if self.rehearsal:
+            self.local_rank = 0
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank)
+        self.dist = None
+        self.collective = self.world > 1 or args.dist   # steps end with the gather of the ranks' tile buffers
+        if self.collective:
+            import torch.distributed as dist
+            self.dist = dist
+            if self.rehearsal:
+                dist.init_process_group("gloo")
+            elif self.world == 1:   # --dist: the N > 1 code path at world size 1 (RCCL communicator of one rank)
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29500 + os.getpid() % 2000}", rank=0, world_size=1,
+                                        device_id=self.device)
+            else:
+                dist.init_process_group("nccl", device_id=self.device)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.scenes = {}
+
+    # ---- scenes and workloads ------------------------------------------------------------------------------------
+    def host_scene(self, path):
+        if path not in self.scenes:
+            self.scenes[path] = self.vpt.HostScene(path)
+        return self.scenes[path]
+
+    def workload(self, scene_path, shader, bounces, resolution, spp, rank=None, world=None):
+        """state of `rank`'s tiles of the frame, resident on this process's GPU, under a FRESH scene handle"""
+        vpt, torch = self.vpt, self.torch
+        rank = self.rank if rank is None else rank
+        world = self.world if world is None else world
+        w = argparse.Namespace(scene_path=scene_path, shader=shader, bounces=bounces, spp=spp, rank=rank, world=world, done=0, kernel_ms=[])
+        w.scene = self.host_scene(scene_path)
+        w.scene_name = os.path.basename(os.path.dirname(os.path.abspath(scene_path)))
+        # params.samples bounds the progressive render; keep it out of reach (and != 1: preview branch)
+        w.params = vpt.PathtraceParams(resolution=resolution, samples=1 << 30, shader=shader, bounces=bounces)
+        w.state = w.scene.make_state(w.params)
+        w.width, w.height = w.state.width, w.state.height
+        w.dev = vpt.DeviceScene(w.scene, self.local_rank)
+        w.layout = vpt.VptLayout(w.width, w.height, self.args.tile, self.args.tile, rank, world)
+        w.slots = vpt.layout_slots(w.layout)
+        w.d_image = torch.zeros((w.slots, 4), dtype=torch.float32, device=self.device)
+        w.d_hits = torch.zeros((w.slots,), dtype=torch.int32, device=self.device)
+        w.d_rng = torch.zeros((w.slots, 2), dtype=torch.int64, device=self.device)
+        vpt.state_upload(w.layout, w.state, w.d_image.data_ptr(), w.d_hits.data_ptr(), w.d_rng.data_ptr())
+        gather = self.collective and world == self.world
+        w.gathered = torch.empty((world * w.slots, 4), dtype=torch.float32, device=self.device) if gather else w.d_image
+        w.frame = torch.empty((w.height, w.width, 4), dtype=torch.float32, device=self.device)
+        w.samples_per_step = w.width * w.height * spp
+        w.gather = gather
+        return w
+
+    def step(self, w, record=True):
+        vpt, torch, dist = self.vpt, self.torch, self.dist
+        w.dev.render_device(w.params, w.layout, w.spp, w.d_image.data_ptr(), w.d_hits.data_ptr(), w.d_rng.data_ptr(), self.stream)
+        w.done += w.spp
+        if record:
+            w.kernel_ms.append(w.dev.last_kernel_ms())
+        if w.gather and self.rehearsal:
+            torch.cuda.synchronize()
+            parts = [torch.empty((w.slots, 4), dtype=torch.float32) for _ in range(w.world)]
+            dist.all_gather(parts, w.d_image.cpu())
+            w.gathered.copy_(torch.cat(parts, 0))
+        elif w.gather:  # tile buffers of all ranks over xGMI, then de-interleave on every rank
+            dist.all_gather_into_tensor(w.gathered, w.d_image)
+        vpt.resolve_device(w.layout, w.gathered.data_ptr(), w.done, w.frame.data_ptr(), self.stream)
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, w, steps, warmup):
+        """W untimed steps, then exactly `steps` steps between two fences; seconds, max over ranks"""
+        for _ in range(warmup):
+            self.step(w, False)
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(w, True)
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cpu" if self.rehearsal else self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def cold_call(self, w):
+        """the first call on w's (fresh) scene handle: no wave costs known yet"""
+        self.torch.cuda.synchronize()
+        tc = time.perf_counter()
+        self.step(w, False)
+        self.torch.cuda.synchronize()
+        ms = (time.perf_counter() - tc) * 1e3
+        return {"ms": round(ms, 3), "value": round(w.samples_per_step / ms * 1e-3, 3), "unit": "Msamples/s"}
+
+    def alone_on_rank0(self, scene_path, shader, bounces, resolution, spp, steps):
+        """N > 1: the same frame on rank 0 alone, for the speed-up (the other ranks wait at the barrier)"""
+        single = None
+        if self.rank == 0:
+            w1 = self.workload(scene_path, shader, bounces, resolution, spp, rank=0, world=1)
+            self.step(w1, False)   # warm-up launch (pilot + order)
+            self.torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(steps):
+                self.step(w1, False)
+            self.torch.cuda.synchronize()
+            single = {"ms_per_step": round((time.perf_counter() - ts) / steps * 1e3, 3), "steps": steps}
+            del w1
+        self.dist.barrier()
+        return single
+
+    # ---- derived records (rank 0) ----------------------------------------------------------------------------------
+    def roofline(self, w):
+        import oracle_lib  # the checker, used here only for the reported CPU baseline and event counts
+        vpt = self.vpt
+        # event counts on a bounded sample of the same workload (oracle, all host threads)
+        cparams = vpt.PathtraceParams(resolution=320, samples=1 << 30, shader=w.shader, bounces=w.bounces)
+        cstate = w.scene.make_state(cparams)
+        counters = oracle_lib.oracle_render(w.scene, cparams, cstate, 4, nthreads=0, counters=True)
+        bps = algorithmic_bytes_per_sample(counters)
+        per_launch_samples = w.samples_per_step / w.world   # this rank's share of a launch
+        mean_ms = sum(w.kernel_ms) / max(1, len(w.kernel_ms))
+        achieved = bps * per_launch_samples / (mean_ms * 1e-3) * 1e-9
+        implicit = w.shader.startswith("implicit")
+        rec = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+               "traffic": None, "traffic_source": None,
+               "kernel": ("vpt_render_kernel<%s>" if implicit else "vpt_mesh_kernel<%s>") % w.shader, "kernel_ms": round(mean_ms, 3),
+               "algorithmic_bytes_per_sample": round(bps, 1)}
+        # memory-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs of
+        # this same command, profiles/tools/profile_config.sh); only quoted for the workload it was measured on
+        tag = {("03_volume", "volpathtrace", 64): "k1", ("05_head1ss_sub", "volpathtrace", 64): "head",
+               ("06_gridsdf_synth", "implicit", 4): "k2"}.get((w.scene_name, w.shader, w.bounces))
+        tfile = profile_file(tag, "hbm_traffic") if tag else None
+        if tfile:
+            t = json.load(open(tfile))
+            if t.get("bytes_per_sample"):
+                rec["traffic"] = round(t["bytes_per_sample"] * per_launch_samples)
+                rec["traffic_source"] = os.path.relpath(tfile, ROOT) + " (committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes, bytes per sample x this launch's samples)"
+        if implicit:   # the HBM yardstick says little about a VALU-bound kernel: wave-level VALU instructions per sample from the committed SQ pass
+            pfile = profile_file(tag, "pmc_summary") if tag else None
+            per_sample = json.load(open(pfile)).get("_derived", {}).get("valu_wave_instructions_per_sample") if pfile else None
+            if per_sample:
+                rec["valu_issue_frac"] = round(per_sample * per_launch_samples / (mean_ms * 1e-3) / VALU_ISSUE_PEAK, 4)
+                rec["valu_source"] = os.path.relpath(pfile, ROOT) + f" ({per_sample:.0f} wave-level VALU instructions per sample) x live samples/s / 1 228.8 G/s"
+        return rec
+
+    def cpu_baseline(self, w):
+        import oracle_lib
+        vpt, args = self.vpt, self.args
+        sres, sspp = (int(x) for x in args.cpu_sample.split("x"))
+        ncores = host_cores()
+        workdir = os.environ.get("TMPDIR", "/tmp")
+        rec = None
+
+        def port(threads, res, spp):   # our CPU restatement, one thread per core: does not oversubscribe
+            sp = vpt.PathtraceParams(resolution=res, samples=1 << 30, shader=w.shader, bounces=w.bounces)
+            st = w.scene.make_state(sp)
+            t1 = time.perf_counter()
+            oracle_lib.oracle_render(w.scene, sp, st, spp, nthreads=threads)
+            dt = time.perf_counter() - t1
+            return {"value": round(st.width * st.height * spp / dt * 1e-6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+                    "sample": f"{w.scene_name} {st.width}x{st.height}x{spp}spp, oracle/vpt_oracle.cpp, {threads} thread(s)"}
+        if oracle_lib.have_reference():
+            *_, info = oracle_lib.reference_render(w.scene_path, w.shader, sres, sspp, w.bounces, workdir=workdir)
+            rec = {"value": round(info["msamples_per_s"], 4), "unit": "Msamples/s", "cores": min(ncores, info["threads"]),
+                   "threads_started": info["threads"], "kind": "reference",
+                   "sample": f"{w.scene_name} {info['width']}x{info['height']}x{sspp}spp, reference renderer (g++ -O2), "
+                             f"{info['threads']} threads (its own hardware_concurrency()) on {ncores} cores"}
+            *_, one = oracle_lib.reference_render(w.scene_path, w.shader, max(64, sres // 2), max(1, sspp // 4), w.bounces, workdir=workdir, noparallel=True)
+            rec["single_thread"] = {"value": round(one["msamples_per_s"], 4), "unit": "Msamples/s", "cores": 1, "kind": "reference",
+                                    "sample": f"{w.scene_name} {one['width']}x{one['height']}x{max(1, sspp // 4)}spp, reference renderer --noparallel"}
+            rec["port"] = port(ncores, sres, max(1, sspp // 2))
+        else:
+            rec = port(ncores, sres, sspp)
+            rec["single_thread"] = port(1, max(64, sres // 2), max(1, sspp // 4))
+        rec["cpu"] = cpu_model()
+        return rec
 
 
 def main():
@@ -70,205 +315,92 @@ def main():
     ap.add_argument("--tile", type=int, default=8)
     ap.add_argument("--balance", action="store_true", help="add per-wave duration statistics of the last launch to the line")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold first-call measurement (N = 1)")
+    ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configs (N = 1) / the config-5 record (N > 1)")
+    ap.add_argument("--dist", action="store_true", help="N = 1: run the N > 1 code path (nccl group, all_gather_into_tensor) at world size 1")
+    ap.add_argument("--dump-frame", default=None, help="write the resolved frame of the last step (float32 h x w x 4) to this .npy")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import vpt_loader
-    vpt = vpt_loader.load()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # VPT_BENCH_REHEARSAL=1: all ranks of an N > 1 job on GPU 0 with gloo (tile buffers staged through the host) - a dry
-    # run of the multi-GPU code path on a one-GPU box; its timings mean nothing and the line says so
-    rehearsal = world > 1 and os.environ.get("VPT_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
+    B = Bench(args)
+    np, world, rank = B.np, B.world, B.rank
+    default_workload = args.scene == SCENE and args.shader == "volpathtrace" and args.bounces == 64 and args.resolution == 1280
     resolution = int(round(args.resolution * (world ** 0.5))) if args.weak else args.resolution
-    scene = vpt.HostScene(args.scene)
-    # params.samples bounds the progressive render; keep it out of reach (and != 1: preview branch)
-    params = vpt.PathtraceParams(resolution=resolution, samples=1 << 30, shader=args.shader, bounces=args.bounces)
-    state = scene.make_state(params)
-    width, height = state.width, state.height
-    dev = vpt.DeviceScene(scene, local_rank)
-    layout = vpt.VptLayout(width, height, args.tile, args.tile, rank, world)
-    slots = vpt.layout_slots(layout)
-    device = torch.device("cuda", local_rank)
-    d_image = torch.zeros((slots, 4), dtype=torch.float32, device=device)
-    d_hits = torch.zeros((slots,), dtype=torch.int32, device=device)
-    d_rng = torch.zeros((slots, 2), dtype=torch.int64, device=device)
-    vpt.state_upload(layout, state, d_image.data_ptr(), d_hits.data_ptr(), d_rng.data_ptr())
-    gathered = torch.empty((world * slots, 4), dtype=torch.float32, device=device) if world > 1 else d_image
-    frame = torch.empty((height, width, 4), dtype=torch.float32, device=device)
-    stream = torch.cuda.current_stream().cuda_stream
-    done = [0]
-    kernel_ms = []
 
-    def step(record):
-        dev.render_device(params, layout, args.spp, d_image.data_ptr(), d_hits.data_ptr(), d_rng.data_ptr(), stream)
-        done[0] += args.spp
-        if record:
-            kernel_ms.append(dev.last_kernel_ms())
-        if rehearsal:
-            torch.cuda.synchronize()
-            parts = [torch.empty((slots, 4), dtype=torch.float32) for _ in range(world)]
-            dist.all_gather(parts, d_image.cpu())
-            gathered.copy_(torch.cat(parts, 0))
-        elif world > 1:  # tile buffers of all ranks over xGMI, then de-interleave on every rank
-            dist.all_gather_into_tensor(gathered, d_image)
-        vpt.resolve_device(layout, gathered.data_ptr(), done[0], frame.data_ptr(), stream)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    fence()
-    elapsed = time.perf_counter() - t0
+    w = B.workload(args.scene, args.shader, args.bounces, resolution, args.spp)
+    elapsed = B.timed(w, args.steps, args.warmup)
+    if args.dump_frame and rank == 0:
+        np.save(args.dump_frame, w.frame.cpu().numpy())
     balance = None
     if args.balance:   # load-balance figures of the last launch (after the timed region): per-wave durations
-        c = dev.last_wave_costs().astype(np.float64) * 1e-5   # ticks of 100 MHz -> ms
+        c = w.dev.last_wave_costs().astype(np.float64) * 1e-5   # ticks of 100 MHz -> ms
         c = c[c > 0]
         balance = {"waves": int(len(c)), "longest_wave_ms": round(float(c.max()), 3), "mean_wave_ms": round(float(c.mean()), 4),
                    "sum_wave_ms": round(float(c.sum()), 1), "p99_wave_ms": round(float(np.quantile(c, 0.99)), 3)}
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # ---- N > 1: the same frame on rank 0 alone, for the speed-up (the other ranks wait at the barrier) ----------
-    single = None
-    if world > 1 and not args.weak:
-        if rank == 0:
-            lay1 = vpt.VptLayout(width, height, args.tile, args.tile, 0, 1)
-            n1 = vpt.layout_slots(lay1)
-            i1 = torch.zeros((n1, 4), dtype=torch.float32, device=device)
-            h1 = torch.zeros((n1,), dtype=torch.int32, device=device)
-            r1 = torch.zeros((n1, 2), dtype=torch.int64, device=device)
-            vpt.state_upload(lay1, state, i1.data_ptr(), h1.data_ptr(), r1.data_ptr())
-            solo_steps = max(1, min(args.steps, 2))
-            for k in range(1 + solo_steps):   # one warm-up launch (pilot + order), then the timed ones
-                if k == 1:
-                    torch.cuda.synchronize()
-                    ts = time.perf_counter()
-                dev.render_device(params, lay1, args.spp, i1.data_ptr(), h1.data_ptr(), r1.data_ptr(), stream)
-                vpt.resolve_device(lay1, i1.data_ptr(), (k + 1) * args.spp, frame.data_ptr(), stream)
-            torch.cuda.synchronize()
-            single = {"ms_per_step": round((time.perf_counter() - ts) / solo_steps * 1e3, 3), "steps": solo_steps}
-            del i1, h1, r1
-        dist.barrier()
-    # ---- N = 1: the first call on a fresh scene handle (no wave costs known: pilot launch + ordered launch) ---------
     cold = None
-    if world == 1 and not args.no_cold:
-        dev2 = vpt.DeviceScene(scene, local_rank)
-        i2, h2, r2 = torch.zeros_like(d_image), torch.zeros_like(d_hits), torch.zeros_like(d_rng)
-        vpt.state_upload(layout, state, i2.data_ptr(), h2.data_ptr(), r2.data_ptr())
-        torch.cuda.synchronize()
-        tc = time.perf_counter()
-        dev2.render_device(params, layout, args.spp, i2.data_ptr(), h2.data_ptr(), r2.data_ptr(), stream)
-        vpt.resolve_device(layout, i2.data_ptr(), args.spp, frame.data_ptr(), stream)
-        torch.cuda.synchronize()
-        cold_ms = (time.perf_counter() - tc) * 1e3
-        cold = {"ms": round(cold_ms, 3), "value": round(width * height * args.spp / cold_ms * 1e-3, 3), "unit": "Msamples/s",
-                "what": "first call on a fresh scene handle: no wave costs known yet, so a pilot launch (spp/64 samples) measures "
-                        "them and the rest runs in its order; `value` above is the steady state (order from the previous launch)"}
-        del dev2, i2, h2, r2
-    scene_name = os.path.basename(os.path.dirname(os.path.abspath(args.scene)))
+    if world == 1 and not args.no_cold:   # a fresh handle, after the timed region (warm clocks)
+        wc = B.workload(args.scene, args.shader, args.bounces, resolution, args.spp)
+        cold = B.cold_call(wc)
+        cold["what"] = ("first call on a fresh scene handle: no wave costs known yet, so a pilot launch (spp/64 samples) measures "
+                        "them and the rest runs in its order; `value` above is the steady state (order from the previous launch)")
+        del wc
+    single = config5 = None
+    if world > 1 and not args.weak:
+        single = B.alone_on_rank0(args.scene, args.shader, args.bounces, resolution, args.spp, max(1, min(args.steps, 2)))
+        if default_workload and not args.no_others:
+            # BASELINE config[4]'s frame, the one ">= 6x at 8 GPUs" can hold on: 03_volume 3840x1600, 256 spp per step
+            w5 = B.workload(SCENE, "volpathtrace", 64, 3840, 256)
+            e5 = B.timed(w5, 2, 2)   # the first call measures tile costs (pilot), the second may split tiles: both warm-up
+            s5 = B.alone_on_rank0(SCENE, "volpathtrace", 64, 3840, 256, 1)
+            if rank == 0:
+                ms5 = e5 / 2 * 1e3
+                config5 = {"workload": f"03_volume volpathtrace bounces=64 {w5.width}x{w5.height}x256spp per step, fixed frame, tiles%{world} "
+                                       "(BASELINE config[4]'s frame at 256 of its 4096 spp per step: cost per sample does not depend on spp)",
+                           "steps": 2, "warmup": 2, "ms_per_step": round(ms5, 3), "value": round(w5.samples_per_step / ms5 * 1e-3, 3),
+                           "unit": "Msamples/s", "kernel_ms_rank0": round(sum(w5.kernel_ms) / len(w5.kernel_ms), 3),
+                           "gather_bytes_per_rank": int(w5.slots * 16), "single_gpu": s5,
+                           "speedup_vs_1gpu": round(s5["ms_per_step"] / ms5, 3)}
+            del w5
+
+    scene_name = w.scene_name
     data_desc = ("reference scene tests/03_volume (real assets), deterministic PCG32 seeds" if args.scene == SCENE else
                  f"{scene_name}: substitute assets (tests/golden/make_scenes.py), deterministic PCG32 seeds")
-    samples_per_step = width * height * args.spp
-    value = samples_per_step * args.steps / elapsed * 1e-6
+    value = w.samples_per_step * args.steps / elapsed * 1e-6
 
-    roofline, cpu_baseline = None, None
     if rank == 0:
-        import oracle_lib  # the checker, used here only for the reported CPU baseline and event counts
-        # --- event counts on a bounded sample of the same workload (oracle, all host threads) ------
-        cres, cspp = 320, 4
-        cparams = vpt.PathtraceParams(resolution=cres, samples=1 << 30, shader=args.shader, bounces=args.bounces)
-        cstate = scene.make_state(cparams)
-        counters = oracle_lib.oracle_render(scene, cparams, cstate, cspp, nthreads=0, counters=True)
-        bps = algorithmic_bytes_per_sample(counters)
-        # this rank's share of a launch
-        per_launch_samples = samples_per_step / world
-        mean_ms = sum(kernel_ms) / max(1, len(kernel_ms))
-        achieved = bps * per_launch_samples / (mean_ms * 1e-3) * 1e-9
-        # memory-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs of
-        # this same command, profiles/tools/profile_config.sh); only quoted for the workload it was measured on
-        traffic = None
-        tag = {("03_volume", "volpathtrace", 64): "k1", ("05_head1ss_sub", "volpathtrace", 64): "head",
-               ("06_gridsdf_synth", "implicit", 4): "k2"}.get((scene_name, args.shader, args.bounces))
-
-        def _version(path):   # profiles/r<round>_<tag>_v<version>_hbm_traffic.json (round 1: r01_v<version>_...), compared numerically
-            import re
-            m = re.search(r"r(\d+)_(?:[a-z0-9]+_)?v(\d+)_", os.path.basename(path))
-            return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_v*_hbm_traffic.json")) +
-                        (glob.glob(os.path.join(ROOT, "profiles", "r01_v*_hbm_traffic.json")) if tag == "k1" else []), key=_version) if tag else []
-        if tfiles:
-            t = json.load(open(tfiles[-1]))
-            if t.get("bytes_per_sample"):
-                traffic = round(t["bytes_per_sample"] * per_launch_samples)
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "kernel": ("vpt_render_kernel<%s>" if args.shader.startswith("implicit") else "vpt_mesh_kernel<%s>") % args.shader, "kernel_ms": round(mean_ms, 3),
-                    "algorithmic_bytes_per_sample": round(bps, 1)}
-        if world == 1 and args.cpu_sample != "0":
-            sres, sspp = (int(x) for x in args.cpu_sample.split("x"))
-            # cores this process may actually use (cgroup / affinity), not the machine's thread count
-            ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            try:  # cgroup v2 CPU quota ("<quota> <period>" or "max <period>")
-                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-                if quota != "max":
-                    ncores = max(1, min(ncores, int(int(quota) / int(period))))
-            except (OSError, ValueError):
-                pass
-            if oracle_lib.have_reference():
-                *_, info = oracle_lib.reference_render(args.scene, args.shader, sres, sspp, args.bounces,
-                                                       workdir=os.environ.get("TMPDIR", "/tmp"))
-                cpu_baseline = {"value": round(info["msamples_per_s"], 4), "unit": "Msamples/s", "cores": min(ncores, info["threads"]),
-                                "threads_started": info["threads"],
-                                "kind": "reference",
-                                "sample": f"{scene_name} {info['width']}x{info['height']}x{sspp}spp, reference renderer (g++ -O2)"}
-            else:
-                sp = vpt.PathtraceParams(resolution=sres, samples=1 << 30, shader=args.shader, bounces=args.bounces)
-                sstate = scene.make_state(sp)
-                t1 = time.perf_counter()
-                oracle_lib.oracle_render(scene, sp, sstate, sspp, nthreads=0)
-                dt = time.perf_counter() - t1
-                cpu_baseline = {"value": round(sstate.width * sstate.height * sspp / dt * 1e-6, 4), "unit": "Msamples/s",
-                                "cores": ncores, "kind": "port",
-                                "sample": f"{scene_name} {sstate.width}x{sstate.height}x{sspp}spp, oracle/vpt_oracle.cpp"}
+        roofline = B.roofline(w)
+        cpu_baseline = B.cpu_baseline(w) if (world == 1 and args.cpu_sample != "0") else None
+        others = None
+        if world == 1 and default_workload and not args.no_others:
+            others = []
+            for name, path, shader, bounces, res, spp in (
+                    ("config3 (tests/05_head1ss: assets missing, substitute scene)", os.path.join(SCENES, "05_head1ss_sub", "head1ss_sub.json"), "volpathtrace", 64, 1280, 64),
+                    ("config4 (tests/06_gridsdf: assets missing, substitute scene with 96^3 + 64^3 grids)", os.path.join(SCENES, "06_gridsdf_synth", "gridsdf_synth.json"), "implicit", 4, 1280, 128),
+                    ("config5's frame on one GPU", SCENE, "volpathtrace", 64, 3840, 64)):
+                wo = B.workload(path, shader, bounces, res, spp)
+                first = B.cold_call(wo)
+                eo = B.timed(wo, 3, 1)
+                ms = eo / 3 * 1e3
+                others.append({"config": name, "workload": f"{wo.scene_name} {shader} bounces={bounces} {wo.width}x{wo.height}x{spp}spp per step",
+                               "steps": 3, "warmup": 1, "ms_per_step": round(ms, 3), "value": round(wo.samples_per_step / ms * 1e-3, 3),
+                               "unit": "Msamples/s", "cold": first, "roofline": B.roofline(wo)})
+                del wo
+        if world == 1:
+            workload_note = ""
+        elif args.weak:
+            workload_note = ", frame grows with N"
+        else:
+            workload_note = (", fixed frame (a pixel's samples are a serial RNG chain: the costliest 8x8 tile bounds the launch, so this frame "
+                             "cannot scale past ~2.4x at 8 GPUs; see config5 for the 3840x1600 frame)")
         line = {
             "metric": "Msamples/sec", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
-            "dtype": "f32", "data": data_desc + (" [REHEARSAL: all ranks on one GPU over gloo - timings are not a measurement]" if rehearsal else ""),
-            "config": {"workload": f"{scene_name} {args.shader} bounces={args.bounces} {width}x{height}x{args.spp}spp per step" + ("" if world == 1 else (", frame grows with N" if args.weak else ", fixed frame")),
-                       "tile": f"{args.tile}x{args.tile}", "parallelism": f"tiles%{world}, costly tiles split into partly filled waves (auto)" if world > 1 else "1gpu",
-                       "samples_per_step": samples_per_step},
+            "dtype": "f32", "data": data_desc + (" [REHEARSAL: all ranks on one GPU over gloo - timings are not a measurement]" if B.rehearsal else ""),
+            "config": {"workload": f"{scene_name} {args.shader} bounces={args.bounces} {w.width}x{w.height}x{args.spp}spp per step" + workload_note,
+                       "tile": f"{args.tile}x{args.tile}",
+                       "parallelism": (f"tiles%{world}, costly tiles split into partly filled waves (auto)" if world > 1 else
+                                       "1gpu + nccl group of one rank (all_gather_into_tensor per step)" if args.dist else "1gpu"),
+                       "samples_per_step": w.samples_per_step},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         if balance:
@@ -278,10 +410,14 @@ def main():
         if single:
             line["single_gpu"] = single
             line["speedup_vs_1gpu"] = round(single["ms_per_step"] / (elapsed / args.steps * 1e3), 3)
+        if config5:
+            line["config5"] = config5
+        if others:
+            line["other_configs"] = others
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if B.dist is not None:
+        B.dist.barrier()
+        B.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

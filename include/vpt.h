@@ -258,18 +258,40 @@ int vpt_render(vpt_scene* scene, const vpt_params* params, int nsamples, int wid
 /* ---- the same over several GPUs of this process ("multi-GPU fan-out is internal", §8(e)) ----------
  * One host thread per GPU; the frame's 8x8-pixel tiles are dealt round-robin (tile t -> devices[t % ndev]); every
  * device holds the whole scene and the state of its own tiles, so rendering needs no communication and the result is
- * bit-identical to vpt_render's (pixels own their RNG streams).  vpt_multi_get_render assembles the frame on
- * devices[0]: the float4 tile buffers travel there over xGMI by grouped RCCL send / receive (RCCL is loaded on first
- * use; ndev == 1 never touches it) and are resolved by the kernel of vpt_resolve_device. */
+ * bit-identical to vpt_render's (pixels own their RNG streams).
+ *
+ * Residency: the tile state (radiance sums, hit counts, PCG32 streams) STAYS ON THE DEVICES between calls
+ * (the reference's pathtrace_state is the same progressive accumulator, yocto_pathtrace.h:57-64).
+ *   vpt_multi_set_state   host pathtrace_state -> devices (pinned staging, one thread per GPU)
+ *   vpt_multi_render      with null image/hits/rng: `nsamples` passes on the resident state, nothing is transferred;
+ *                         with host pointers: the contract of vpt_render - the arrays are current after the call
+ *                         (yocto_pathtrace.cpp:1081-1090) - and the upload is skipped when they still are the state
+ *                         this handle stored there after its last render (same size, same *samples_io > 0, and 64
+ *                         probe pixels spread over the frame - RNG words, sum, hit count - unchanged).  A caller that
+ *                         edits the arrays in place between two calls announces it with vpt_multi_set_state (any change
+ *                         of size or sample count, e.g. a fresh make_state, is seen without it); VPT_MULTI_RESIDENT=0
+ *                         makes every call upload.
+ *   vpt_multi_get_state   devices -> host arrays, on demand
+ *   vpt_multi_get_render  get_render of the resident state, assembled on devices[0]: the float4 tile buffers travel there
+ *                         over xGMI by grouped RCCL send / receive (RCCL is bound on first use, a copy the process already
+ *                         carries is reused; one device never touches it unless VPT_MULTI_FORCE_RCCL=1, which sends the
+ *                         buffer to itself through a one-rank communicator) or, where RCCL cannot be had, by
+ *                         hipMemcpyPeerAsync; then the kernel of vpt_resolve_device.
+ * Like vpt_render, a render fails with VPT_ERR_HIP if a wave of the implicit kernel gave up on its watchdog. */
 typedef struct vpt_multi vpt_multi;
 int  vpt_multi_create(const vpt_scene_desc* desc, const int* devices, int ndev, vpt_multi** out);
 void vpt_multi_destroy(vpt_multi* m);
 int  vpt_multi_device_count(const vpt_multi* m);
-/* pathtrace_samples over all GPUs of `m`: the contract of vpt_render */
+/* how vpt_multi_get_render moves the parts: "rccl", "peer-copy" (several devices, no RCCL) or "local" (one device) */
+const char* vpt_multi_transport(const vpt_multi* m);
+int  vpt_multi_set_state(vpt_multi* m, int width, int height, const float* image_rgba, const int32_t* hits,
+                         const uint64_t* rng, int samples);
+int  vpt_multi_get_state(vpt_multi* m, float* image_rgba, int32_t* hits, uint64_t* rng, int* samples);
+/* pathtrace_samples over all GPUs of `m` (see above for null host pointers) */
 int  vpt_multi_render(vpt_multi* m, const vpt_params* params, int nsamples, int width, int height,
                       float* image_rgba, int32_t* hits, uint64_t* rng, int* samples_io);
-/* get_render (yocto_pathtrace.cpp:1105-1116) of the state the last vpt_multi_render left on the devices: row-major
- * float4 image * (1 / samples) into the caller's host buffer, gathered and resolved on devices[0] */
+/* get_render (yocto_pathtrace.cpp:1105-1116) of the resident state: row-major float4 image * (1 / samples) into the
+ * caller's host buffer, gathered and resolved on devices[0] */
 int  vpt_multi_get_render(vpt_multi* m, float* image_rgba);
 
 /* ---- device-resident state (bench / multi-GPU; buffers owned by the caller, e.g. torch) */
@@ -305,6 +327,9 @@ int vpt_resolve_srgb8_device(const vpt_layout* layout, const void* d_tiles_all_r
  * launch.  Like vpt_render it returns VPT_ERR_HIP if a wave of the implicit kernel gave up on its watchdog (a wave
  * that has not finished after 300 s leaves the kernel instead of holding the GPU: a defect, never a workload). */
 int vpt_last_kernel_ms(vpt_scene* scene, float* ms);
+/* the watchdog check alone (synchronous; the caller has waited for its launches): VPT_ERR_HIP if any wave of the
+ * implicit kernel on this scene handle has given up since the handle was created */
+int vpt_check_watchdog(vpt_scene* scene);
 
 /* How long every wave of the last vpt_render_device launch on this scene ran, in ticks of the 100 MHz wall clock:
  * what the next launch's longest-first order is made from, exposed for load-balance analysis (critical path = the

@@ -17,11 +17,11 @@ shift
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-small="--steps 1 --warmup 1 --cpu-sample 0 --no-cold"
+small="--steps 1 --warmup 1 --cpu-sample 0 --no-cold --no-others"
 for p in $passes; do
   case $p in
     plain) python3 bench.py "$@" > $out/bench.json 2> $out/bench.err ;;
-    stats) rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py "$@" --cpu-sample 0 --no-cold > $out/stats.log 2>&1 ;;
+    stats) rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py "$@" --cpu-sample 0 --no-cold --no-others > $out/stats.log 2>&1 ;;
     fetch) rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $out/fetch -o run -- python3 bench.py "$@" $small > $out/fetch.log 2>&1 ;;
     write) rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $out/write -o run -- python3 bench.py "$@" $small > $out/write.log 2>&1 ;;
     sq)    rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD \

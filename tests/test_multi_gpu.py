@@ -43,3 +43,128 @@ def test_multi_errors(vpt, scene03):
                                       st.rngs.ctypes.data, C.byref(n))
         assert rc == -4
         raise vpt.VptError(vpt.hip.vpt_last_error().decode())
+
+
+def test_state_stays_resident_between_calls(vpt, scene03, dev03):
+    """the tile state lives on the devices across sample batches.  Upload once, render in batches with no
+    transfers, download on demand: the same bits as the single-GPU entry point; the host-pointer form skips its upload when
+    the caller's arrays still are what it stored there, and sees every way a caller can hand it another state."""
+    p = vpt.PathtraceParams(resolution=200, samples=12, shader="volpathtrace", bounces=64)
+    ref = scene03.make_state(p)
+    dev03.pathtrace_samples(ref, p, 12)
+    multi = vpt.MultiDeviceScene(scene03, [0, 0, 0])
+    st = scene03.make_state(p)
+    multi.set_state(st)
+    assert multi.render_resident(p, 5) == 5 and multi.render_resident(p, 4) == 9 and multi.render_resident(p, 100) == 12
+    assert (st.image == 0).all() and st.samples == 0              # nothing came back on its own
+    frame = multi.get_render(st.width, st.height)
+    assert np.array_equal(frame.view(np.uint32), vpt.get_render(ref).view(np.uint32))
+    multi.get_state(st)
+    assert st.samples == 12 and (st.hits == 12).all()
+    assert np.array_equal(st.image.view(np.uint32), ref.image.view(np.uint32)) and np.array_equal(st.rngs, ref.rngs)
+
+    # host-pointer calls: upload skipped on the second call (probes match) - and the result is the same either way
+    half = scene03.make_state(p)
+    dev03.pathtrace_samples(half, p, 3)
+    a = scene03.make_state(p)
+    multi.pathtrace_samples(a, p, 1)
+    multi.pathtrace_samples(a, p, 2)
+    assert np.array_equal(a.image.view(np.uint32), half.image.view(np.uint32)) and np.array_equal(a.rngs, half.rngs)
+    # the caller swaps in another state with the same sample count: a fresh state advanced by another handle
+    b = scene03.make_state(p)
+    dev03.pathtrace_samples(b, p, 3)
+    b.image[:] = 0                                               # ... and edited (the probes see it)
+    multi.pathtrace_samples(b, p, 1)
+    expect = scene03.make_state(p)
+    dev03.pathtrace_samples(expect, p, 3)
+    expect.image[:] = 0
+    dev03.pathtrace_samples(expect, p, 1)
+    assert np.array_equal(b.image.view(np.uint32), expect.image.view(np.uint32)) and np.array_equal(b.rngs, expect.rngs)
+    # a reset (make_state: samples == 0) is always uploaded
+    c = scene03.make_state(p)
+    multi.pathtrace_samples(c, p, 12)
+    assert np.array_equal(c.image.view(np.uint32), ref.image.view(np.uint32))
+    # rendering on the devices without a matching resident state is an error, not a stale image
+    with pytest.raises(vpt.VptError):
+        multi._resident = (st.width, st.height, 5)
+        multi.render_resident(p, 1)
+
+
+def test_rccl_entry_points_run_on_one_gpu(vpt, scene03, dev03, monkeypatch):
+    """VPT_MULTI_FORCE_RCCL=1: a one-rank communicator (ncclCommInitAll), the tile buffer sent to itself with grouped
+    ncclSend / ncclRecv, ncclCommDestroy - every RCCL call of vpt_multi.cpp, on the one GPU this box has.  Same frame."""
+    monkeypatch.setenv("VPT_MULTI_FORCE_RCCL", "1")
+    p = vpt.PathtraceParams(resolution=200, samples=4, shader="volpathtrace", bounces=64)
+    ref = scene03.make_state(p)
+    dev03.pathtrace_samples(ref, p, 4)
+    multi = vpt.MultiDeviceScene(scene03, [0])
+    assert multi.transport() == "rccl"
+    st = scene03.make_state(p)
+    multi.pathtrace_samples(st, p, 4)
+    for _ in range(2):                                           # the communicator is reused
+        frame = multi.get_render(st.width, st.height)
+        assert np.array_equal(frame.view(np.uint32), vpt.get_render(ref).view(np.uint32))
+    multi.close()
+
+
+def test_failed_rccl_init_falls_back_to_peer_copies(vpt, scene03, dev03, monkeypatch, tmp_path):
+    """ncclCommInitAll failing (no P2P, busy device ...) must neither crash nor fail the handle: the frame assembly
+    falls back to hipMemcpyPeerAsync.  A stub library whose ncclCommInitAll returns an error stands in for RCCL."""
+    import subprocess
+    src = tmp_path / "stub.c"
+    src.write_text('int ncclCommInitAll(void** c, int n, const int* d) { for (int i = 0; i < n; i++) c[i] = (void*)(long)(i + 1); return 2; }\n'
+                   'int destroyed = 0;\nint ncclCommDestroy(void* c) { destroyed++; return 0; }\nint ncclGroupStart() { return 2; }\nint ncclGroupEnd() { return 2; }\n'
+                   'int ncclSend() { return 2; }\nint ncclRecv() { return 2; }\nconst char* ncclGetErrorString(int r) { return "stub failure"; }\n')
+    lib = tmp_path / "librccl_stub.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(src), "-o", str(lib)])
+    monkeypatch.setenv("VPT_MULTI_FORCE_RCCL", "1")
+    monkeypatch.setenv("VPT_MULTI_RCCL_LIB", str(lib))
+    p = vpt.PathtraceParams(resolution=128, samples=2, shader="volpathtrace", bounces=64)
+    ref = scene03.make_state(p)
+    dev03.pathtrace_samples(ref, p, 2)
+    multi = vpt.MultiDeviceScene(scene03, [0])
+    assert multi.transport() == "local"
+    st = scene03.make_state(p)
+    multi.pathtrace_samples(st, p, 2)
+    assert np.array_equal(multi.get_render(st.width, st.height).view(np.uint32), vpt.get_render(ref).view(np.uint32))
+    import ctypes as C
+    assert C.c_int.in_dll(C.CDLL(str(lib)), "destroyed").value == 1   # the communicator the failed call had created was destroyed
+
+
+def test_watchdog_fails_the_multi_render(vpt, monkeypatch):
+    """A wave of the implicit kernel that gives up on its watchdog leaves an incomplete image: vpt_multi_render (what the
+    host drop-in and ypathtrace call) must fail like vpt_render does.  VPT_K2_WATCHDOG_MS=0 makes every wave give up."""
+    import os
+    from conftest import GOLDEN
+    scene = vpt.HostScene(os.path.join(GOLDEN, "scenes", "06_gridsdf_synth", "gridsdf_synth.json"))
+    p = vpt.PathtraceParams(resolution=96, samples=4, shader="implicit", bounces=4)
+    st = scene.make_state(p)
+    good = vpt.MultiDeviceScene(scene, [0, 0])
+    good.pathtrace_samples(st, p, 2)
+    assert st.samples == 2
+    monkeypatch.setenv("VPT_K2_WATCHDOG_MS", "0")
+    bad = vpt.MultiDeviceScene(scene, [0, 0])
+    st2 = scene.make_state(p)
+    with pytest.raises(vpt.VptError, match="watchdog"):
+        bad.pathtrace_samples(st2, p, 2)
+    assert st2.samples == 0
+    single = vpt.DeviceScene(scene, 0)
+    with pytest.raises(vpt.VptError, match="watchdog"):
+        single.pathtrace_samples(scene.make_state(p), p, 2)
+
+
+@pytest.mark.parametrize("ndev", [2, 4, 8])
+def test_distinct_gpus_when_the_box_has_them(vpt, scene03, dev03, ndev):
+    """the RCCL gather between DISTINCT devices: runs the first time a multi-GPU node is available (skipped on the
+    one-GPU boxes of this pool, where the tests above stand in for it)"""
+    if vpt.device_count() < ndev:
+        pytest.skip(f"needs {ndev} GPUs, this box has {vpt.device_count()}")
+    p = vpt.PathtraceParams(resolution=320, samples=4, shader="volpathtrace", bounces=64)
+    ref = scene03.make_state(p)
+    dev03.pathtrace_samples(ref, p, 4)
+    multi = vpt.MultiDeviceScene(scene03, list(range(ndev)))
+    st = scene03.make_state(p)
+    multi.pathtrace_samples(st, p, 4)
+    assert np.array_equal(st.image.view(np.uint32), ref.image.view(np.uint32)) and np.array_equal(st.rngs, ref.rngs)
+    assert np.array_equal(multi.get_render(st.width, st.height).view(np.uint32), vpt.get_render(ref).view(np.uint32))
+    assert multi.transport() in ("rccl", "peer-copy")

@@ -110,6 +110,11 @@ hip.vpt_multi_destroy.restype = None
 hip.vpt_multi_device_count.argtypes = [_p]
 hip.vpt_multi_render.argtypes = [_p, C.POINTER(VptParams), C.c_int, C.c_int, C.c_int, _p, _p, _p, C.POINTER(C.c_int)]
 hip.vpt_multi_get_render.argtypes = [_p, _p]
+hip.vpt_multi_transport.argtypes = [_p]
+hip.vpt_multi_transport.restype = C.c_char_p
+hip.vpt_multi_set_state.argtypes = [_p, C.c_int, C.c_int, _p, _p, _p, C.c_int]
+hip.vpt_multi_get_state.argtypes = [_p, _p, _p, _p, C.POINTER(C.c_int)]
+hip.vpt_check_watchdog.argtypes = [_p]
 hip.vpt_resolve_srgb8_device.argtypes = [C.POINTER(VptLayout), _p, C.c_int, _p, _p]
 hip.vpt_selftest_reciprocal.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
 hip.vpt_selftest_light_cdf.argtypes = [_p, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
@@ -302,11 +307,37 @@ class MultiDeviceScene:
         self.handle = out
 
     def pathtrace_samples(self, state: PathtraceState, params: PathtraceParams, count: int = 1) -> None:
+        """host state in, host state out (the contract of vpt_render); the upload is skipped while `state` still is what the
+        last call stored (include/vpt.h)"""
         abi = params.to_abi()
         samples = C.c_int(state.samples)
         _check(hip.vpt_multi_render(self.handle, C.byref(abi), count, state.width, state.height, state.image.ctypes.data,
                                     state.hits.ctypes.data, state.rngs.ctypes.data, C.byref(samples)), "vpt_multi_render")
         state.samples = samples.value
+
+    # -- resident state: upload once, render in batches without transfers, download on demand ---------
+    def set_state(self, state: PathtraceState) -> None:
+        _check(hip.vpt_multi_set_state(self.handle, state.width, state.height, state.image.ctypes.data, state.hits.ctypes.data,
+                                       state.rngs.ctypes.data, state.samples), "vpt_multi_set_state")
+        self._resident = (state.width, state.height, state.samples)
+
+    def render_resident(self, params: PathtraceParams, count: int = 1) -> int:
+        """`count` passes on the state the devices hold; returns the sample count reached"""
+        abi = params.to_abi()
+        w, h, n = self._resident
+        samples = C.c_int(n)
+        _check(hip.vpt_multi_render(self.handle, C.byref(abi), count, w, h, None, None, None, C.byref(samples)), "vpt_multi_render")
+        self._resident = (w, h, samples.value)
+        return samples.value
+
+    def get_state(self, state: PathtraceState) -> None:
+        samples = C.c_int(0)
+        _check(hip.vpt_multi_get_state(self.handle, state.image.ctypes.data, state.hits.ctypes.data, state.rngs.ctypes.data,
+                                       C.byref(samples)), "vpt_multi_get_state")
+        state.samples = samples.value
+
+    def transport(self) -> str:
+        return hip.vpt_multi_transport(self.handle).decode()
 
     def get_render(self, width: int, height: int) -> np.ndarray:
         out = np.zeros((height, width, 4), np.float32)

@@ -1268,11 +1268,13 @@ static int launch_implicit(const launch_ctx& L) {
   if (lds > 64 * 1024) return fail(VPT_ERR_UNSUPPORTED, "scene has too many SDFs for the implicit kernel's LDS copy of their records (%d + %d)", s->d.num_sdfs, s->d.num_vol_instances);
   sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, nullptr};
   s->last_waves = (int)L.grid.x;
+  unsigned long long watchdog_ticks = VPT_K2_WATCHDOG_TICKS;
+  if (const char* e = getenv("VPT_K2_WATCHDOG_MS")) watchdog_ticks = strtoull(e, nullptr, 10) * 100000ull;   // tests of the error path
   // the instance for the features this scene's lights have (VPT_FEAT_*): SDF scenes without emissive meshes run one without the mesh-light walks
   if ((s->light_features & (VPT_FEAT_LARGE_LIGHTS | VPT_FEAT_SMALL_LIGHTS)) == 0 && !getenv("VPT_NO_LEAN"))
-    hipLaunchKernelGGL((vpt_render_kernel<K, VPT_FEAT_SDF_LIGHTS>), L.grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog);
+    hipLaunchKernelGGL((vpt_render_kernel<K, VPT_FEAT_SDF_LIGHTS>), L.grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog, watchdog_ticks);
   else
-    hipLaunchKernelGGL((vpt_render_kernel<K, VPT_FEAT_ALL>), L.grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog);
+    hipLaunchKernelGGL((vpt_render_kernel<K, VPT_FEAT_ALL>), L.grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog, watchdog_ticks);
   return sched_update(s, L.grid.x, L.st);
 }
 
@@ -1330,7 +1332,9 @@ int vpt_last_wave_costs(vpt_scene* s, unsigned* ticks, int capacity, int* count)
 }
 
 // synchronous: waves of the implicit kernel that hit their watchdog since the scene was created (a defect, never a workload)
-static int check_watchdog(vpt_scene* s) {
+int vpt_check_watchdog(vpt_scene* s) {
+  if (!s) return fail(VPT_ERR_INVALID_ARG, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
   unsigned n = 0;
   HIP_TRY(hipMemcpy(&n, s->d_watchdog, 4, hipMemcpyDeviceToHost));
   if (n) return fail(VPT_ERR_HIP, "%u wave(s) of the implicit kernel gave up after their watchdog time: the result is incomplete", n);
@@ -1342,7 +1346,7 @@ int vpt_last_kernel_ms(vpt_scene* s, float* ms) {
   if (!s->timed) return fail(VPT_ERR_INVALID_ARG, "no launch recorded");
   HIP_TRY(hipEventSynchronize(s->ev1));
   HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
-  return check_watchdog(s);
+  return vpt_check_watchdog(s);
 }
 
 int vpt_resolve_device(const vpt_layout* layout, const void* d_tiles_all_ranks, int samples, void* d_image_rowmajor, void* stream) {
@@ -1403,7 +1407,7 @@ int vpt_render(vpt_scene* s, const vpt_params* params, int nsamples, int width, 
   if (int rc = vpt_render_device(s, params, &lay, todo, s->s_image, s->s_hits, s->s_rng, nullptr)) return rc;
   // the row-major staging still holds the frame that was uploaded, and this single-rank layout owns every pixel
   if (int rc = state_download(&lay, s->s_image, s->s_hits, s->s_rng, image_rgba, hits, rng, nullptr, rows, true)) return rc;
-  if (int rc = check_watchdog(s)) return rc;
+  if (int rc = vpt_check_watchdog(s)) return rc;
   *samples_io += todo;
   return VPT_OK;
 }

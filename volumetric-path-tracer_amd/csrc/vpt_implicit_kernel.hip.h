@@ -44,7 +44,7 @@
 #define VPT_K2_SHADE_AT 24   // lanes waiting for the shading block before the wave runs it (8: -11 %, 16: -4 %, 24: best, 32: -5 %)
 #endif
 #ifndef VPT_K2_WATCHDOG_TICKS
-#define VPT_K2_WATCHDOG_TICKS 30000000000ull   // 300 s: two orders of magnitude above the longest wave of any test workload
+#define VPT_K2_WATCHDOG_TICKS 30000000000ull   // 300 s: two orders of magnitude above the longest wave of any test workload (the launch passes it as an argument; VPT_K2_WATCHDOG_MS overrides it for the tests of the error path)
 #endif
 #ifndef VPT_K2_LIGHT_INLINE
 #define VPT_K2_LIGHT_INLINE 0   // 1: an SDF light's pdf march runs to its end inside the shading block (measured: 145 against 179 Msamples/s); 0: as M_LIGHT trips of its own
@@ -140,7 +140,7 @@ VPT_DEV float lights_pdf_k2(const DScene& sc, f3 position, f3 direction, int max
 
 template <int SH, int FEAT>
 __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DScene sc, DParams pr, float4* __restrict__ image,
-    int* __restrict__ hits, ulonglong2* __restrict__ rngs, int stack_cap, sched_cfg sched, unsigned* __restrict__ watchdog) {
+    int* __restrict__ hits, ulonglong2* __restrict__ rngs, int stack_cap, sched_cfg sched, unsigned* __restrict__ watchdog, unsigned long long watchdog_ticks) {
   extern __shared__ int lds_stack[];
   lane_stack stk;   // binary-node stack: only the pdf walk of an emissive mesh with a real BVH uses it
   stk.base = lds_stack + threadIdx.x;
@@ -196,8 +196,8 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
   bool gave_up = false;
   while (true) {
     // every wave reaches an exit: the state machine ends when all lanes are M_DONE; should a defect ever keep it from
-    // getting there, the wave gives up after VPT_K2_WATCHDOG_TICKS of the 100 MHz clock and the launch reports it
-    if (((++trips) & 255) == 0 && clock_ticks(trips) - wave_start > VPT_K2_WATCHDOG_TICKS) {
+    // getting there, the wave gives up after watchdog_ticks (VPT_K2_WATCHDOG_TICKS) of the 100 MHz clock and the launch reports it
+    if (((++trips) & 255) == 0 && clock_ticks(trips) - wave_start > watchdog_ticks) {
       gave_up = true;
       break;
     }

@@ -361,6 +361,30 @@ int vpt_intersect(vpt_scene* scene, int n, const float* rays, int instance, int3
  * Synchronous.  SURVEY §8(f) row 4 (load-time callers of the hot path). */
 int vpt_build_bvh(int device, const float* bboxes, int n, vpt_bvh_node* nodes, int capacity, int* num_nodes, int32_t* primitives);
 
+/* The float32 half of one level of the reference's Catmull-Clark subdivision (tesselate_catmullclark,
+ * libs/yocto_pathtrace/yocto_pathtrace.cpp:1119-1226) on the device.  The caller supplies the level's
+ * topology (integers: host/vpt_tesselate.cpp builds it as the reference does): the cage's edges in the reference's numbering,
+ * its faces (a quad with z == w is a triangle), the refined faces, and per refined vertex - old vertices first, then one per
+ * edge, then one per face - its kind (`valence`: 0 locked boundary, 1 creased boundary, 2 smooth) and the items whose centroids
+ * the reference's averaging pass adds to it, IN THE ORDER ITS LOOPS REACH THEM (items[offsets[v] .. offsets[v + 1]): valence 0:
+ * the vertex id, once per contribution; valence 1: vertex pairs (a, b) of crease edges; valence 2: refined face ids).  The
+ * device computes the refined points, the averages in that order and the correction: `new_vertices` (num_vertices + num_edges
+ * + num_faces entries of `dim` floats) holds the same bits as the reference's `vert` after the level.  Synchronous; every
+ * index is validated on the host before a kernel runs. */
+typedef struct vpt_subdiv_level {
+  int32_t        dim;                                   /* floats per vertex: 3 (positions) or 2 (texcoords) */
+  int32_t        num_vertices, num_edges, num_faces;    /* of the cage                                        */
+  int32_t        num_new_faces;
+  const int32_t* edges;                                 /* int2 [num_edges]                                   */
+  const int32_t* faces;                                 /* int4 [num_faces]                                   */
+  const int32_t* new_faces;                             /* int4 [num_new_faces]                               */
+  const int32_t* valence;                               /* [num_vertices + num_edges + num_faces]             */
+  const int32_t* offsets;                               /* [that + 1]                                         */
+  const int32_t* items;
+  int64_t        num_items;
+} vpt_subdiv_level;
+int vpt_subdivide_vertices(int device, const vpt_subdiv_level* level, const float* vertices, float* new_vertices);
+
 /* Device self-test of an arithmetic shortcut the kernels rely on for bit-exact parity: the reference divides
  * (1 / d per ray, yocto_bvh.cpp:806-808; 1 / det per triangle, yocto_geometry.h:690), the kernels use
  * v_rcp_f32 + one Newton step where every lane's operand has a biased exponent in 1..250.  Runs all 2^32 bit

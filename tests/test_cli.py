@@ -111,3 +111,23 @@ def test_cli_gpubvh_renders_the_same_file(tmp_path):
         r = run(*common, "--output", out, *extra)
         assert r.returncode == 0, r.stderr
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+@pytest.mark.gpu
+def test_cli_renders_subdivision_surfaces_like_the_reference(tmp_path):
+    """tests/01_surface (the reference's OBJ cages, one substituted): load_scene reads the cages, tesselate_surfaces refines
+    them on the host or - --gputess - with the vertex arithmetic on the GPU: the same JPEG, and the reference's own where
+    oracle/_ref exists"""
+    import oracle_lib as O
+    scene = os.path.join(GOLDEN, "scenes", "01_surface_min", "surface_min.json")
+    a, b, c = str(tmp_path / "host.jpg"), str(tmp_path / "gpu.jpg"), str(tmp_path / "ref.jpg")
+    common = ["--scene", scene, "--shader", "eyelight", "--samples", "2", "--resolution", "128"]
+    for out, extra in ((a, []), (b, ["--gputess", "--gpubvh"])):
+        r = run(*common, "--output", out, *extra)
+        assert r.returncode == 0, r.stderr
+    assert open(a, "rb").read() == open(b, "rb").read()
+    if O.have_reference():   # eyelight draws no light samples: every pixel replays the reference's stream (measured), so the 8-bit files agree
+        O.reference_render(scene, "eyelight", 128, 2, 4, output=c, workdir=str(tmp_path))
+        from PIL import Image
+        mine, ref = np.asarray(Image.open(a), np.int32), np.asarray(Image.open(c), np.int32)
+        assert mine.shape == ref.shape and np.abs(mine - ref).max() <= 2 and (mine != ref).mean() < 0.01

@@ -36,32 +36,39 @@ from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-def _check_against_reference(oracle, scene, params, spp, g, ref_img, ref_rng, name, min_same, min_ok, min_stable):
-    """the strict check of the module docstring; g = device state, ref_* = the reference's state"""
+def _check_against_reference(oracle, scene, params, spp, g, ref_img, ref_rng, name, min_same, min_ok, min_stable, pixels=None):
+    """the strict check of the module docstring; g = device state, ref_* = the reference's state.
+    pixels: row-major indices of the pixels the reference state holds (a seeded sample of a full-size frame): the check and
+    its shares are over those pixels only"""
     assert g.samples == spp and (g.hits == spp).all()                 # integer: exact
+    chosen = np.ones(ref_rng.shape[:2], bool)
+    if pixels is not None:
+        chosen[:] = False
+        chosen.reshape(-1)[pixels] = True
     same = np.all(g.rngs == ref_rng, axis=-1)                        # pixels that replayed the reference's paths
     close = np.all(np.isclose(g.image, ref_img, rtol=2e-3, atol=2e-3 * spp), axis=-1)
     fresh = lambda: scene.make_state(params)                         # noqa: E731
-    u_stream, u_rad = oracle.unstable_pixels(scene, params, spp, ref_img, ref_rng, fresh, rounds=16)
+    u_stream, u_rad = oracle.unstable_pixels(scene, params, spp, ref_img, ref_rng, fresh, rounds=16, pixels=pixels)
     stable = ~(u_stream | u_rad)
     ok = same & close
-    left = np.flatnonzero((stable & ~ok).reshape(-1))               # disagreeing pixels the 16 frame-wide patterns did not move
+    left = np.flatnonzero((chosen & stable & ~ok).reshape(-1))      # disagreeing pixels the 16 frame-wide patterns did not move
     deep = 0
     if 0 < len(left) <= 64:                                          # stage 2: 2048 more patterns on those pixels only
         d_stream, d_rad = oracle.unstable_pixels(scene, params, spp, ref_img, ref_rng, fresh, rounds=2048, pixels=left, first_seed=1000)
         deep = int((d_stream | d_rad).sum())
         stable &= ~(d_stream | d_rad)
-    bad = stable & ~ok
-    rest = ~stable
-    print(f"{name}: streams identical {same.mean():.4f}; matching the reference {ok.mean():.4f}; stable under 1-ulp libm nudges {stable.mean():.4f} "
-          f"(stream-unstable {u_stream.mean():.4f}, radiance-unstable {u_rad.mean():.4f}, shown unstable only by the deep stage {deep}); "
+    bad = chosen & stable & ~ok
+    rest = chosen & ~stable
+    share = lambda m: float(m[chosen].mean())                        # noqa: E731
+    print(f"{name}: {int(chosen.sum())} pixels; streams identical {share(same):.4f}; matching the reference {share(ok):.4f}; stable under 1-ulp libm nudges {share(stable):.4f} "
+          f"(stream-unstable {share(u_stream):.4f}, radiance-unstable {share(u_rad):.4f}, shown unstable only by the deep stage {deep}); "
           f"unstable pixels matching {ok[rest].mean() if rest.any() else 1.0:.4f}; worst abs diff on stable pixels "
-          f"{float(np.abs(g.image - ref_img)[stable].max()):.3g}")
+          f"{float(np.abs(g.image - ref_img)[chosen & stable].max()):.3g}")
     assert not bad.any(), (name, int(bad.sum()), np.argwhere(bad)[:10].tolist())
-    assert same.mean() >= min_same, (name, same.mean())
-    assert ok.mean() >= min_ok, (name, ok.mean())
-    assert stable.mean() >= min_stable, (name, stable.mean())
-    m_g, m_r = g.image[..., :3].mean(), ref_img[..., :3].mean()      # image-level agreement including the diverged pixels
+    assert share(same) >= min_same, (name, share(same))
+    assert share(ok) >= min_ok, (name, share(ok))
+    assert share(stable) >= min_stable, (name, share(stable))
+    m_g, m_r = g.image[chosen][..., :3].mean(), ref_img[chosen][..., :3].mean()      # image-level agreement including the diverged pixels
     assert abs(m_g - m_r) <= 0.03 * abs(m_r) + 1e-6
 
 
@@ -157,18 +164,23 @@ def test_virtual_ranks_on_one_gpu_are_bit_identical(vpt, scene03, dev03, nranks,
     assert np.array_equal(frame.cpu().numpy().view(np.uint32), expect.view(np.uint32))
 
 
-FULL_SIZE = {  # BASELINE.json configs at their full frame sizes: (scene, shader, resolution, bounces, expected (w, h), spp)
-    "config2_03_volume_1280": ("03_volume/volume.json", "volpathtrace", 1280, 64, (1280, 533), 8),
-    "config3_05_head_1280": ("05_head1ss_sub/head1ss_sub.json", "volpathtrace", 1280, 64, (1280, 1280), 4),
-    "config4_06_gridsdf_1280": ("06_gridsdf_synth/gridsdf_synth.json", "implicit", 1280, 4, (1280, 533), 4),
-    "config5_03_volume_3840": ("03_volume/volume.json", "volpathtrace", 3840, 64, (3840, 1600), 2),
+FULL_SIZE = {  # BASELINE.json configs at their full frame sizes: (scene, shader, resolution, bounces, expected (w, h), spp,
+    # floors on the sampled pixels' (identical streams, matching the reference, stable) shares: just under the MI355X-measured ones)
+    "config2_03_volume_1280": ("03_volume/volume.json", "volpathtrace", 1280, 64, (1280, 533), 8, (0.998, 0.998, 0.88)),     # measured 1.0000 1.0000 0.8954
+    "config3_05_head_1280": ("05_head1ss_sub/head1ss_sub.json", "volpathtrace", 1280, 64, (1280, 1280), 4, (0.998, 0.998, 0.995)),   # 1.0000 1.0000 1.0000
+    "config4_06_gridsdf_1280": ("06_gridsdf_full/gridsdf_full.json", "implicit", 1280, 4, (1280, 533), 4, (0.994, 0.987, 0.935)),   # 0.9978 0.9924 0.9508
+    "config5_03_volume_3840": ("03_volume/volume.json", "volpathtrace", 3840, 64, (3840, 1600), 2, (0.998, 0.998, 0.935)),   # 1.0000 1.0000 0.9491 (gpurun_out/r3b/tests.log, round 3)
 }
+FULL_SIZE_PIXELS = 4096
 
 
 @pytest.mark.parametrize("name", sorted(FULL_SIZE))
 def test_full_size_properties(vpt, oracle, name):
-    """The BASELINE frame sizes: size-independent properties + a low-resolution statistical cross-check on the oracle."""
-    scene_file, shader, res, bounces, size, spp = FULL_SIZE[name]
+    """The BASELINE frame sizes: size-independent properties of the whole frame + the STRICT per-pixel check of the module
+    docstring on a seeded sample of 4 096 pixels, which the oracle (bit-identical to the reference) renders at the full
+    resolution (vpt_oracle_render_pixels): same RNG end state, radiance within 2e-3, unless the reference's own value of
+    that pixel moves under 1-ulp libm nudges."""
+    scene_file, shader, res, bounces, size, spp, floors = FULL_SIZE[name]
     scene = vpt.HostScene(os.path.join(GOLDEN, "scenes", scene_file))
     dev = vpt.DeviceScene(scene, 0)
     p = vpt.PathtraceParams(resolution=res, samples=1 << 20, shader=shader, bounces=bounces)
@@ -184,13 +196,21 @@ def test_full_size_properties(vpt, oracle, name):
     dev.pathtrace_samples(h, p, 1)
     dev.pathtrace_samples(h, p, spp - 1)
     assert np.array_equal(h.image.view(np.uint32), g.image.view(np.uint32)) and np.array_equal(h.rngs, g.rngs)
-    # same scene at 1/8 of the width on the oracle: mean radiance within MC error
-    q = vpt.PathtraceParams(resolution=res // 8, samples=1 << 20, shader=shader, bounces=bounces)
-    c = scene.make_state(q)
-    oracle.oracle_render(scene, q, c, 8)
-    ratio = (g.image[..., :3].mean() / spp) / (c.image[..., :3].mean() / 8)
-    print(name, "mean radiance device / oracle(low res):", ratio)
-    assert abs(ratio - 1) < 0.05
+    # pixel-exact parity on a seeded sample of the full-size frame (a quarter of it from the frame's last rows and columns,
+    # where ragged tiles and the end of the launch order live)
+    rng = np.random.default_rng(size[0] * 7 + size[1])
+    w, hgt = size
+    pix = rng.choice(w * hgt, FULL_SIZE_PIXELS * 3 // 4, replace=False)
+    edge_y = rng.integers(hgt - 16, hgt, FULL_SIZE_PIXELS // 8) * w + rng.integers(0, w, FULL_SIZE_PIXELS // 8)
+    edge_x = rng.integers(0, hgt, FULL_SIZE_PIXELS // 8) * w + rng.integers(w - 16, w, FULL_SIZE_PIXELS // 8)
+    pix = np.unique(np.concatenate([pix, edge_y, edge_x])).astype(np.int32)
+    q = vpt.PathtraceParams(resolution=res, samples=spp, shader=shader, bounces=bounces)
+    ref = scene.make_state(q)
+    oracle.oracle_render(scene, q, ref, spp, nthreads=0, pixels=pix)
+    untouched = np.ones(w * hgt, bool)
+    untouched[pix] = False
+    assert (ref.image.reshape(-1, 4)[untouched] == 0).all()   # the oracle rendered the sampled pixels only
+    _check_against_reference(oracle, scene, q, spp, g, ref.image, ref.rngs, name + f" {w}x{hgt}x{spp}", *floors, pixels=pix)
 
 
 def _rms_vs_check(vpt, state, check_name):
@@ -243,6 +263,9 @@ MIN_EXTRA = {  # name -> floors on (identical streams, pixels matching the refer
     # shares (in the comments; gpurun_out/r2c/tests.log, 2026-10-04)
     "surf_path_96_4": (0.997, 0.997, 0.985),        # 0.9995 0.9995 0.9927
     "surf_normal_96_1": (0.998, 0.998, 0.998), "surf_eye_96_2": (0.998, 0.998, 0.998),   # 1.0000 1.0000 1.0000
+    "surf_subdiv_96_4": (0.997, 0.997, 0.985),      # 0.9995 0.9995 0.9930 (round 3: the scene now holds the reference's subdivision cages)
+    "subdiv_path_96_4": (0.998, 0.998, 0.995), "subdiv_normal_96_2": (0.998, 0.998, 0.998),   # 1.0000 1.0000 0.9993 / 1.0000
+    "sdf_full_implicit_96_4": (0.994, 0.989, 0.94),   # 0.9982 0.9943 0.9523 (gpurun_out/r3b/tests.log, round 3)
     "head_vol_96_4": (0.998, 0.998, 0.995),         # 1.0000 1.0000 0.9999
     "sdf_implicit_96_4": (0.993, 0.985, 0.93),      # 0.9969 0.9909 0.9432
     "sdf_nomis_96_4": (0.993, 0.987, 0.925),        # 0.9966 0.9922 0.9362

@@ -1,0 +1,155 @@
+"""tesselate_surfaces (libs/yocto_pathtrace/yocto_pathtrace.cpp:1119-1280): Catmull-Clark subdivision of
+face-varying cages, split_facevarying, quads_to_triangles, displacement, smooth normals - and the OBJ reader that feeds it.
+
+Pinning: tests/golden/substitute_stats.json holds the FNV-1a hashes the REFERENCE printed for positions / normals / texcoords /
+triangles of every tesselated shape (oracle/_ref/ref_driver --stats, tests/golden/make_fixtures.py): the reference's own cages
+of tests/01_surface (cube 4 levels, spot 2, suzanne 2) + a displaced sphere, and the hand-made corner cases of 08_subdiv_synth.
+The host path must reproduce the hashes (CPU tests); the device path (vpt_subdivide_vertices) must reproduce the host path bit
+for bit (GPU tests)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+SCENES = ["01_surface_min/surface_min.json", "08_subdiv_synth/subdiv_synth.json"]
+
+
+def _stats(vpt, scene_file, **kw):
+    return json.loads(vpt.HostScene(os.path.join(GOLDEN, "scenes", scene_file), **kw).stats())
+
+
+@pytest.mark.parametrize("scene_file", SCENES)
+def test_tesselated_shapes_hash_equal_to_the_reference(vpt, scene_file):
+    golden = json.load(open(os.path.join(GOLDEN, "substitute_stats.json")))[scene_file]
+    mine = _stats(vpt, scene_file)
+    subdivided = [s["shape"] for s in json.load(open(os.path.join(GOLDEN, "scenes", scene_file)))["subdivs"]]
+    assert len(subdivided) == 4
+    for i in subdivided:
+        a, b = golden["shapes"][i], mine["shapes"][i]
+        assert b["quads"] == 0 and b["triangles"] > 0                      # quads_to_triangles
+        for key in ("positions", "normals", "texcoords", "triangles", "pos_fnv", "nrm_fnv", "uv_fnv", "tri_fnv", "bvh_nodes_fnv", "bvh_prims_fnv"):
+            assert a[key] == b[key], (scene_file, i, key)
+    assert mine == golden                                                  # and everything downstream of it (BVHs, lights)
+
+
+def test_the_references_cages_have_the_expected_sizes(vpt):
+    shapes = _stats(vpt, SCENES[0])["shapes"]
+    # cube-subdiv: 6 quads, 4 levels -> 6 * 4^4 quads -> 3072 triangles; spot / suzanne: 2 levels; the displaced sphere keeps its 6144 quads
+    assert shapes[4]["triangles"] == 6 * 4 ** 4 * 2 and shapes[2]["triangles"] == 6144 * 2
+    assert shapes[1]["triangles"] == 6368 and shapes[3]["triangles"] == 15752
+    corner = _stats(vpt, SCENES[1])["shapes"]
+    assert corner[2]["normals"] == 0 and corner[2]["texcoords"] == 0       # smooth = false, cage without texcoords
+    assert corner[4]["normals"] == 0                                       # displaced with smooth = false: normals dropped after the displacement
+
+
+def _load_shape_via_scene(vpt, tmp_path, obj_text, name="a.obj", subdiv=None):
+    """load an OBJ through load_scene (the only public way in): returns the scene's stats or raises VptError"""
+    (tmp_path / name).write_text(obj_text)
+    scene = {"asset": {"version": "4.2"}, "cameras": [{"name": "c", "aspect": 1.0}], "materials": [{"name": "m", "type": "matte", "color": [0.5, 0.5, 0.5]}],
+             "shapes": [{"name": "s", "uri": name}], "instances": [{"name": "i", "shape": 0, "material": 0}]}
+    if subdiv is not None:
+        scene["subdivs"] = [dict(subdiv, shape=0, uri=name)]
+    (tmp_path / "scene.json").write_text(json.dumps(scene))
+    return json.loads(vpt.HostScene(str(tmp_path / "scene.json")).stats())
+
+
+def test_obj_reader_follows_the_references_rules(vpt, tmp_path):
+    # vertices are unified per distinct (position, texcoord, normal) triple in order of first appearance; one 4-corner face
+    # turns every face into a quad (triangles become z == w); negative indices count from the end; comments and unknown
+    # statements are skipped (yocto_modelio.cpp:1952-2072, 2349-2356)
+    text = ("# a comment\nmtllib nothing.mtl\no thing\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 2 0 0 # trailing comment\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+            "usemtl x\nf 1/1 2/2 3/3 4/4\nf 2/1 5/2 3/3\ns off\nf -4/1 -1/2 -3/4\n")
+    st = _load_shape_via_scene(vpt, tmp_path, text)["shapes"][0]
+    # distinct triples: 1/1 2/2 3/3 4/4 | 2/1 5/2 (3/3 seen) | (2/1 seen) 5/2 seen, 3/4 new -> 7 vertices
+    assert (st["positions"], st["texcoords"], st["normals"], st["quads"], st["triangles"]) == (7, 7, 0, 3, 0)
+    tri_only = _load_shape_via_scene(vpt, tmp_path, "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 2 0\nf 1 2 3 4 5\n")["shapes"][0]
+    assert (tri_only["triangles"], tri_only["quads"], tri_only["positions"]) == (3, 0, 5)   # a pentagon is fanned
+    for bad, why in (("v 0 0\nf 1 1 1\n", "parse error"), ("v 0 0 0\nf 1 2 3\n", "parse error"), ("v 0 0 0\nv 1 0 0\n", "empty shape"),
+                     ("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2 3\n", "parse error")):
+        with pytest.raises(vpt.VptError, match=why):
+            _load_shape_via_scene(vpt, tmp_path, bad)
+    with pytest.raises(vpt.VptError, match="a.stl: unknown format"):
+        _load_shape_via_scene(vpt, tmp_path, "solid\n", name="a.stl")
+    # point / line elements are outside the hot-path scope: loaded, then rejected when the scene is flattened
+    with pytest.raises(vpt.VptError):
+        _load_shape_via_scene(vpt, tmp_path, "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\nl 1 2\n")
+
+
+def test_a_subdiv_replaces_its_shape_entirely(vpt, tmp_path):
+    # face-varying cage: 8 positions, 24 texcoords; one level -> 6 * 4 quads, split per distinct (position, normal, texcoord)
+    cube = open(os.path.join(GOLDEN, "scenes", "01_surface_min", "subdivs", "cube-subdiv.obj")).read()
+    flat = _load_shape_via_scene(vpt, tmp_path, cube)["shapes"][0]
+    assert (flat["positions"], flat["quads"]) == (24, 6)
+    one = _load_shape_via_scene(vpt, tmp_path, cube, subdiv={"subdivisions": 1, "smooth": True})["shapes"][0]
+    assert (one["quads"], one["triangles"]) == (0, 48) and one["normals"] == one["positions"] == one["texcoords"]
+    zero = _load_shape_via_scene(vpt, tmp_path, cube, subdiv={"subdivisions": 0})["shapes"][0]
+    assert (zero["positions"], zero["triangles"]) == (24, 12)   # no level: the cage itself, its own normals, triangulated
+
+
+def test_catmullclark_levels_are_consistent(vpt):
+    """structure of one level (counts, Euler characteristic, boundary handling) on meshes small enough to check by hand"""
+    quads = np.array([[0, 1, 4, 3], [1, 2, 5, 4], [3, 4, 7, 6], [4, 5, 8, 7]], np.int32)           # an open 2 x 2 grid
+    verts = np.array([[x, y, 0.25 * x * y] for y in range(3) for x in range(3)], np.float32)
+    q1, v1 = vpt.catmullclark(quads, verts)
+    assert len(q1) == 16 and len(v1) == 9 + 12 + 4
+    # a corner of an open mesh is creased: the mean of the midpoints of its two half boundary edges
+    assert np.array_equal(v1[[0, 2, 6, 8], :2], np.float32([[0.125, 0.125], [1.875, 0.125], [0.125, 1.875], [1.875, 1.875]]))
+    ql, vl = vpt.catmullclark(quads, verts[:, :2].copy(), lock_boundary=True)
+    assert np.array_equal(vl[[0, 2, 6, 8]], verts[[0, 2, 6, 8], :2])                               # locked boundary: (x + x) / 2 == x
+    assert np.array_equal(q1, ql)
+    tri = np.array([[0, 1, 2, 2]], np.int32)                                                       # one triangle -> three quads around its centroid
+    qt, vt = vpt.catmullclark(tri, np.float32([[0, 0, 0], [3, 0, 0], [0, 3, 0]]))
+    assert len(qt) == 3 and len(vt) == 3 + 3 + 1 and (qt[:, 2] == 6).all()
+    with pytest.raises(vpt.VptError):
+        vpt.catmullclark(np.array([[0, 1, 2, 9]], np.int32), verts)
+
+
+def _random_mesh(rng, n):
+    """an n x n grid with holes, some cells split into two triangles, two cells welded into a bow tie"""
+    idx = lambda x, y: y * (n + 1) + x
+    quads = []
+    for y in range(n):
+        for x in range(n):
+            r = rng.random()
+            if r < 0.15:
+                continue
+            a, b, c, d = idx(x, y), idx(x + 1, y), idx(x + 1, y + 1), idx(x, y + 1)
+            if r < 0.35:
+                quads += [[a, b, c, c], [a, c, d, d]]
+            else:
+                quads.append([a, b, c, d])
+    verts = rng.normal(size=((n + 1) ** 2, 3)).astype(np.float32)
+    return np.array(quads, np.int32), verts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,lock", [(3, False), (2, True), (3, True), (2, False)])
+def test_device_levels_equal_host_levels_bit_for_bit(vpt, dev03, dim, lock):
+    rng = np.random.default_rng(5 + dim + 2 * lock)
+    for n in (1, 2, 7, 40):
+        quads, verts = _random_mesh(rng, n)
+        if len(quads) == 0:
+            continue
+        verts = np.ascontiguousarray(verts[:, :dim])
+        for level in range(3):
+            qh, vh = vpt.catmullclark(quads, verts, lock)
+            qd, vd = vpt.catmullclark(quads, verts, lock, device=0)
+            assert np.array_equal(qh, qd) and np.array_equal(vh.view(np.uint32), vd.view(np.uint32)), (n, level)
+            quads, verts = qh, vh
+    cube = np.array([[0, 1, 2, 3], [4, 5, 6, 7], [1, 4, 7, 2], [5, 0, 3, 6], [3, 2, 7, 6], [1, 0, 5, 4]], np.int32)
+    pos = np.float32([[-1, 0, 1], [1, 0, 1], [1, 2, 1], [-1, 2, 1], [1, 0, -1], [-1, 0, -1], [-1, 2, -1], [1, 2, -1]])[:, :dim].copy()
+    for level in range(6):                                                                          # 6 * 4^6 = 24 576 quads
+        qh, vh = vpt.catmullclark(cube, pos, lock)
+        qd, vd = vpt.catmullclark(cube, pos, lock, device=0)
+        assert np.array_equal(vh.view(np.uint32), vd.view(np.uint32))
+        cube, pos = qh, vh
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_file", SCENES)
+def test_device_tesselated_scenes_equal_the_reference(vpt, dev03, scene_file):
+    golden = json.load(open(os.path.join(GOLDEN, "substitute_stats.json")))[scene_file]
+    assert _stats(vpt, scene_file, tess_device=0) == golden

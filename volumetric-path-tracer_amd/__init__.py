@@ -124,6 +124,9 @@ hip.vpt_spheretrace.argtypes = [_p, C.c_int, _p, C.c_int, C.c_int, _p, _p]
 hip.vpt_eval_lobes.argtypes = [_p, C.c_int, _p, _p]
 host.vpth_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
 host.vpth_scene_load.restype = _p
+host.vpth_scene_load_ex.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+host.vpth_scene_load_ex.restype = _p
+host.vpth_catmullclark.argtypes = [_p, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, C.POINTER(C.c_int), _p, C.POINTER(C.c_int), C.c_char_p, C.c_int]
 host.vpth_scene_free.argtypes = [_p]
 host.vpth_scene_free.restype = None
 host.vpth_scene_desc.argtypes = [_p]
@@ -168,13 +171,29 @@ def build_bvh(bboxes: np.ndarray, device: Optional[int] = 0):
     return nodes[:count.value].copy(), prims[:n].copy()
 
 
+def catmullclark(quads: np.ndarray, verts: np.ndarray, lock_boundary: bool = False, device: Optional[int] = None):
+    """one level of the reference's tesselate_catmullclark (yocto_pathtrace.cpp:1119-1226) on an (n, 4) int32 quad array (z == w: a
+    triangle) and an (m, 2 | 3) float32 vertex array: (new quads, new vertices).  device: GPU index for the vertex arithmetic."""
+    quads = np.ascontiguousarray(quads, np.int32).reshape(-1, 4)
+    verts = np.ascontiguousarray(verts, np.float32)
+    n, (m, dim) = len(quads), verts.shape
+    qo, vo = np.zeros((4 * n, 4), np.int32), np.zeros((m + 5 * n, dim), np.float32)
+    nq, nv = C.c_int(), C.c_int()
+    err = C.create_string_buffer(512)
+    if host.vpth_catmullclark(quads.ctypes.data, n, verts.ctypes.data, m, dim, int(lock_boundary), -1 if device is None else device,
+                              qo.ctypes.data, C.byref(nq), vo.ctypes.data, C.byref(nv), err, len(err)) != 0:
+        raise VptError(err.value.decode())
+    return qo[:nq.value].copy(), vo[:nv.value].copy()
+
+
 class HostScene:
     """load_scene + tesselate_surfaces + make_bvh + make_lights, flattened for the C-ABI."""
 
-    def __init__(self, filename: str, bvh_device: Optional[int] = None):
-        """bvh_device: build the BVHs on that GPU (make_bvh_device / vpt_build_bvh) instead of on the host - same arrays"""
+    def __init__(self, filename: str, bvh_device: Optional[int] = None, tess_device: Optional[int] = None):
+        """bvh_device: build the BVHs on that GPU (make_bvh_device / vpt_build_bvh) instead of on the host - same arrays;
+        tess_device: the vertex arithmetic of tesselate_surfaces on that GPU (vpt_subdivide_vertices) - same mesh"""
         err = C.create_string_buffer(1024)
-        self.handle = host.vpth_scene_load(os.fsencode(filename), err, len(err))
+        self.handle = host.vpth_scene_load_ex(os.fsencode(filename), -1 if tess_device is None else tess_device, err, len(err))
         if not self.handle:
             raise VptError(err.value.decode())
         self.filename = filename

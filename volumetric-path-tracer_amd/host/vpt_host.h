@@ -94,6 +94,16 @@ struct volume_instance {
   float   scalef = 1;
   frame3f frame  = {};
 };
+struct subdiv_data {  // yocto_scene.h:161-183: face-varying control cage + subdivision / displacement settings
+  vector<vec4i> quadspos = {}, quadsnorm = {}, quadstexcoord = {};
+  vector<vec3f> positions = {}, normals = {};
+  vector<vec2f> texcoords = {};
+  int   subdivisions = 0;
+  bool  catmullclark = true, smooth = true;
+  float displacement     = 0;
+  int   displacement_tex = invalidid;
+  int   shape            = invalidid;
+};
 struct scene_data {
   vector<camera_data>      cameras       = {};
   vector<instance_data>    instances     = {};
@@ -104,7 +114,7 @@ struct scene_data {
   vector<volume_data>      volumes       = {};
   vector<volume_instance>  vol_instances = {};
   vector<sdf_data>         sdfs          = {};
-  int                      num_subdivs   = 0;  // counted, not tesselated (out of scope)
+  vector<subdiv_data>      subdivs       = {};
   string                   copyright     = "";
 };
 
@@ -163,7 +173,27 @@ bvh_scene        make_bvh_device(const scene_data& scene, const pathtrace_params
 // build_bvh over `n` boxes {min.xyz, max.xyz} on the host (what make_bvh runs per shape and for the instances)
 bvh_data         build_bvh_host(const float* bboxes, int n);
 pathtrace_lights make_lights(const scene_data& scene, const pathtrace_params& params);
-void             tesselate_surfaces(scene_data& scene);  // throws if the scene has subdivs
+// tesselate_surfaces (yocto_pathtrace.cpp:1119-1280): Catmull-Clark subdivision of every subdiv's cage (positions with
+// creased boundaries, texcoords with locked boundaries), split_facevarying, quads_to_triangles, displacement along the
+// vertex normals by the mean of the displacement texture (- 0.5 for 8-bit ones), smooth normals; replaces the subdiv's shape.
+// Host arithmetic in the reference's order: the same float bits (tests/golden/*_stats.json hold the reference's hashes).
+void             tesselate_surfaces(scene_data& scene);
+// one level of the reference's tesselate_catmullclark (cpp:1119-1226) on a quad mesh whose vertices have `dim` (2 or 3)
+// floats; a quad with z == w is a triangle.  quads / verts are replaced by the next level's.
+void             tesselate_catmullclark(vector<vec4i>& quads, vector<float>& verts, int dim, bool lock_boundary);
+// The two halves of a level.  Topology (integers): the refined faces and, per refined vertex, the ordered list of items the
+// reference's averaging pass adds to it (layout: vpt_subdiv_level of include/vpt.h).  Vertices (float32): host form.
+struct subdiv_level {
+  int           nv = 0, ne = 0, nf = 0;
+  vector<int>   edges;    // 2 per edge
+  vector<vec4i> faces, tquads;
+  vector<int>   valence, offsets, items;
+};
+void catmullclark_topology(const vector<vec4i>& quads, int num_vertices, bool lock_boundary, subdiv_level& level);
+void subdivide_vertices(const subdiv_level& level, int dim, const vector<float>& verts, vector<float>& out);
+// Extension: the same with the per-level vertex arithmetic (edge and face points, the averaging pass in face order,
+// the correction pass) on GPU `device` through vpt_subdivide_vertices; topology stays on the host.  Same bits.
+void             tesselate_surfaces_device(scene_data& scene, int device = 0);
 // Progressively computes an image: ONE sample per pixel per call, on the GPU (vpt_render).
 // Throws std::runtime_error("sampler unknown") for a bad shader (reference cpp:947-950) and
 // std::runtime_error with vpt_last_error() if the HIP path is unavailable — there is no CPU
@@ -201,10 +231,11 @@ void flatten_scene(flat_scene& flat, const scene_data& scene, const bvh_scene& b
     const pathtrace_lights& lights);
 vpt_params to_abi(const pathtrace_params& params);
 
-// ---- scene / image IO (yocto_sceneio.h:89-211 subset: JSON 4.2, binary+ascii PLY, PNG, HDR,
-//      .sdf text/binary) ----------------------------------------------------------------------
+// ---- scene / image IO (yocto_sceneio.h:89-211 subset: JSON 4.2, binary+ascii PLY, OBJ geometry (v / vn / vt / f / l / p),
+//      PNG, HDR, .sdf text/binary) ----------------------------------------------------------------------
 bool load_scene(const string& filename, scene_data& scene, string& error);
 bool load_shape(const string& filename, shape_data& shape, string& error, bool flip_texcoord);
+bool load_subdiv(const string& filename, subdiv_data& subdiv, string& error);
 bool load_texture(const string& filename, texture_data& texture, string& error);
 bool load_volume(const string& filename, volume_data& vol, bool binary, string& error);
 bool save_image(const string& filename, const color_image& image, string& error);

@@ -32,12 +32,14 @@ uint64_t fnv1a(const vector<T>& v) { return fnv1a(v.data(), v.size() * sizeof(T)
 
 extern "C" {
 
-void* vpth_scene_load(const char* filename, char* err, int errlen) {
+// tess_device >= 0: the vertex arithmetic of tesselate_surfaces on that GPU (tesselate_surfaces_device: same mesh)
+void* vpth_scene_load_ex(const char* filename, int tess_device, char* err, int errlen) {
   try {
     auto h     = std::make_unique<host_scene>();
     auto error = string{};
     if (!load_scene(filename, h->scene, error)) return set_error(err, errlen, error), nullptr;
-    tesselate_surfaces(h->scene);
+    if (tess_device >= 0) tesselate_surfaces_device(h->scene, tess_device);
+    else tesselate_surfaces(h->scene);
     auto params = pathtrace_params{};
     h->bvh      = make_bvh(h->scene, params);
     h->lights   = make_lights(h->scene, params);
@@ -45,6 +47,35 @@ void* vpth_scene_load(const char* filename, char* err, int errlen) {
     return h.release();
   } catch (const std::exception& e) {
     return set_error(err, errlen, e.what()), nullptr;
+  }
+}
+void* vpth_scene_load(const char* filename, char* err, int errlen) { return vpth_scene_load_ex(filename, -1, err, errlen); }
+// one level of tesselate_catmullclark on a quad mesh with `dim` floats per vertex (host arithmetic, or GPU `device` >= 0 for the
+// vertex half): quads_out has room for 4 * nquads entries, verts_out for (nverts + 4 * nquads + nquads) * dim floats (edges <= 4 per face)
+int vpth_catmullclark(const int32_t* quads, int nquads, const float* verts, int nverts, int dim, int lock_boundary, int device, int32_t* quads_out,
+    int* nquads_out, float* verts_out, int* nverts_out, char* err, int errlen) {
+  try {
+    auto q = vector<vec4i>((size_t)nquads);
+    memcpy((void*)q.data(), quads, (size_t)nquads * 16);
+    for (auto& f : q)
+      for (auto v : {f.x, f.y, f.z, f.w})
+        if (v < 0 || v >= nverts) throw std::invalid_argument{"face index out of range"};
+    auto v = vector<float>(verts, verts + (size_t)nverts * dim);
+    if (device < 0) tesselate_catmullclark(q, v, dim, lock_boundary != 0);
+    else {
+      auto L = subdiv_level{};
+      catmullclark_topology(q, nverts, lock_boundary != 0, L);
+      auto next = vector<float>((size_t)(L.nv + L.ne + L.nf) * dim);
+      auto desc = vpt_subdiv_level{dim, L.nv, L.ne, L.nf, (int)L.tquads.size(), L.edges.data(), &L.faces.data()->x, &L.tquads.data()->x,
+          L.valence.data(), L.offsets.data(), L.items.data(), (int64_t)L.items.size()};
+      if (vpt_subdivide_vertices(device, &desc, v.data(), next.data()) != VPT_OK) throw std::runtime_error{vpt_last_error()};
+      v = std::move(next), q = std::move(L.tquads);
+    }
+    memcpy(quads_out, q.data(), q.size() * 16), memcpy(verts_out, v.data(), v.size() * 4);
+    *nquads_out = (int)q.size(), *nverts_out = (int)(v.size() / (size_t)dim);
+    return 0;
+  } catch (const std::exception& e) {
+    return set_error(err, errlen, e.what()), -1;
   }
 }
 // rebuild the scene's BVHs on GPU `device` (make_bvh_device) and flatten again; 0 on success

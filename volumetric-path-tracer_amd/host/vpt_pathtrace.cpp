@@ -188,11 +188,7 @@ bvh_scene make_bvh_device(const scene_data& scene, const pathtrace_params&, int 
   return make_bvh_on(device, scene);
 }
 
-void tesselate_surfaces(scene_data& scene) {
-  if (scene.num_subdivs != 0)
-    throw std::invalid_argument{
-        "subdivs are outside the hot-path scope (reference yocto_pathtrace.cpp:1119-1280)"};
-}
+// tesselate_surfaces: host/vpt_tesselate.cpp
 
 // =============================================================================================
 // make_lights — serial float32 running sums.  yocto_pathtrace.cpp:983-1049

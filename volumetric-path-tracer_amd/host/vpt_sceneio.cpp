@@ -5,6 +5,7 @@
 // (yocto_sceneio.cpp:885-967).  Written from the file formats, not from the reference's parsers.
 #include <zlib.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <sstream>
+#include <tuple>
 
 #include "vpt_host.h"
 
@@ -262,13 +264,7 @@ double read_binary(const uint8_t*& p, const uint8_t* end, ply_type t, bool big_e
 }
 }  // namespace
 
-bool load_shape(const string& filename, shape_data& shape, string& error, bool flip_texcoord) {
-  shape    = {};
-  auto ext = path_extension(filename);
-  if (ext != ".ply") {
-    error = filename + ": unknown format";  // OBJ/STL are outside the hot-path scope
-    return false;
-  }
+static bool load_ply_shape(const string& filename, shape_data& shape, string& error, bool flip_texcoord) {
   auto data = vector<uint8_t>{};
   if (!read_file(filename, data, error)) return false;
   auto read_error = [&]() {
@@ -421,6 +417,233 @@ bool load_shape(const string& filename, shape_data& shape, string& error, bool f
     return false;
   }
   return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// OBJ geometry (yocto_modelio.cpp:1952-2072 load_obj(obj_shape), :2336-2488 accessors): v / vn / vt / f / l / p,
+// negative indices, polygons fanned; everything else (materials, groups, objects) is skipped as the reference skips it.
+// Two forms, as in the reference: vertices unified per distinct (position, texcoord, normal) triple in order of first
+// appearance (load_shape), or face-varying index triples kept apart (load_fvshape -> load_subdiv).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct obj_vertex { int position = 0, texcoord = 0, normal = 0; };
+struct obj_element { int size = 0; char etype = 'f'; };
+struct obj_raw {
+  vector<vec3f>       positions, normals;
+  vector<vec2f>       texcoords;
+  vector<obj_vertex>  vertices;
+  vector<obj_element> elements;
+};
+void skip_ws(const char*& p, const char* end) {
+  while (p < end && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n')) p++;
+}
+bool parse_float(const char*& p, const char* end, float& v) {   // correctly rounded like the reference's fast_float
+  skip_ws(p, end);
+  if (p >= end) return false;
+  auto tmp = string(p, (size_t)std::min<ptrdiff_t>(end - p, 63));
+  auto stop = (char*)nullptr;
+  v = std::strtof(tmp.c_str(), &stop);
+  if (stop == tmp.c_str()) return false;
+  p += stop - tmp.c_str();
+  return true;
+}
+bool parse_int(const char*& p, const char* end, int& v) {
+  skip_ws(p, end);
+  if (p >= end) return false;
+  auto tmp = string(p, (size_t)std::min<ptrdiff_t>(end - p, 31));
+  auto stop = (char*)nullptr;
+  v = (int)std::strtol(tmp.c_str(), &stop, 10);
+  if (stop == tmp.c_str()) return false;
+  p += stop - tmp.c_str();
+  return true;
+}
+bool parse_obj_vertex(const char*& p, const char* end, obj_vertex& v) {   // "p", "p/t", "p//n", "p/t/n" (yocto_modelio.cpp:1480-1497)
+  v = {};
+  if (!parse_int(p, end, v.position)) return false;
+  if (p < end && *p == '/') {
+    p++;
+    if (p < end && *p == '/') {
+      p++;
+      if (!parse_int(p, end, v.normal)) return false;
+    } else {
+      if (!parse_int(p, end, v.texcoord)) return false;
+      if (p < end && *p == '/') {
+        p++;
+        if (!parse_int(p, end, v.normal)) return false;
+      }
+    }
+  }
+  return true;
+}
+bool load_obj_raw(const string& filename, obj_raw& obj, string& error) {
+  auto data = vector<uint8_t>{};
+  if (!read_file(filename, data, error)) return false;
+  auto parse_error = [&]() {
+    error = filename + ": parse error";
+    return false;
+  };
+  auto cur = (const char*)data.data(), file_end = cur + data.size();
+  while (cur < file_end) {
+    auto line_end = cur;
+    while (line_end < file_end && *line_end != '\n') line_end++;
+    auto p = cur, end = line_end;
+    cur = line_end < file_end ? line_end + 1 : file_end;
+    for (auto c = p; c < end; c++)   // remove_comment
+      if (*c == '#') {
+        end = c;
+        break;
+      }
+    skip_ws(p, end);
+    if (p >= end) continue;
+    auto cmd = string{};
+    while (p < end && *p != ' ' && *p != '\t' && *p != '\r') cmd += *p++;
+    if (cmd == "v" || cmd == "vn") {
+      auto v = vec3f{};
+      if (!parse_float(p, end, v.x) || !parse_float(p, end, v.y) || !parse_float(p, end, v.z)) return parse_error();
+      (cmd == "v" ? obj.positions : obj.normals).push_back(v);
+    } else if (cmd == "vt") {
+      auto v = vec2f{};
+      if (!parse_float(p, end, v.x) || !parse_float(p, end, v.y)) return parse_error();
+      obj.texcoords.push_back(v);
+    } else if (cmd == "f" || cmd == "l" || cmd == "p") {
+      auto& element = obj.elements.emplace_back();
+      element.etype = cmd[0];
+      skip_ws(p, end);
+      while (p < end) {
+        auto vert = obj_vertex{};
+        if (!parse_obj_vertex(p, end, vert)) return parse_error();
+        if (vert.position == 0) break;
+        if (vert.position < 0) vert.position = (int)obj.positions.size() + vert.position + 1;
+        if (vert.texcoord < 0) vert.texcoord = (int)obj.texcoords.size() + vert.texcoord + 1;
+        if (vert.normal < 0) vert.normal = (int)obj.normals.size() + vert.normal + 1;
+        // the reference trusts the file; the device path must not
+        if (vert.position < 1 || vert.position > (int)obj.positions.size() || vert.texcoord < 0 || vert.texcoord > (int)obj.texcoords.size() ||
+            vert.normal < 0 || vert.normal > (int)obj.normals.size())
+          return parse_error();
+        obj.vertices.push_back(vert);
+        element.size += 1;
+        skip_ws(p, end);
+      }
+    }
+  }
+  return true;
+}
+// faces of an obj as quads (a polygon with n != 4 corners is fanned into degenerate quads z == w), one index kind at a time
+template <typename Get>
+void obj_fan_quads(const obj_raw& obj, vector<vec4i>& quads, Get get) {
+  auto cur = 0;
+  for (auto& element : obj.elements) {
+    if (element.etype == 'f') {
+      auto at = [&](int k) { return get(obj.vertices[(size_t)(cur + k)]) - 1; };
+      if (element.size == 4) quads.push_back({at(0), at(1), at(2), at(3)});
+      else
+        for (auto c = 2; c < element.size; c++) quads.push_back({at(0), at(c - 1), at(c), at(c)});
+    }
+    cur += element.size;
+  }
+}
+bool load_obj_shape(const string& filename, shape_data& shape, string& error, bool flip_texcoord) {
+  auto obj = obj_raw{};
+  if (!load_obj_raw(filename, obj, error)) return false;
+  // one vertex per distinct index triple, numbered by first appearance (yocto_modelio.cpp:2036-2068)
+  auto seen = std::map<std::tuple<int, int, int>, int>{};
+  for (auto& v : obj.vertices) {
+    auto triple = std::make_tuple(v.position, v.texcoord, v.normal);
+    auto it     = seen.find(triple);
+    if (it == seen.end()) {
+      auto index = (int)seen.size();
+      shape.positions.push_back(obj.positions[(size_t)v.position - 1]);
+      if (v.normal > 0) shape.normals.push_back(obj.normals[(size_t)v.normal - 1]);
+      if (v.texcoord > 0) shape.texcoords.push_back(obj.texcoords[(size_t)v.texcoord - 1]);
+      seen.emplace(triple, index);
+      v.position = index + 1;
+    } else {
+      v.position = it->second + 1;
+    }
+  }
+  // a file that gives normals / texcoords to some vertices only leaves the reference with arrays of different lengths
+  if ((!shape.normals.empty() && shape.normals.size() != shape.positions.size()) ||
+      (!shape.texcoords.empty() && shape.texcoords.size() != shape.positions.size())) {
+    error = filename + ": parse error";
+    return false;
+  }
+  if (flip_texcoord)
+    for (auto& uv : shape.texcoords) uv.y = 1 - uv.y;
+  // get_faces (yocto_modelio.cpp:2349-2356): any 4-corner face makes the whole mesh quads, else fanned triangles
+  auto any_quad = false;
+  for (auto& e : obj.elements) any_quad |= e.etype == 'f' && e.size == 4;
+  if (any_quad) obj_fan_quads(obj, shape.quads, [](const obj_vertex& v) { return v.position; });
+  else {
+    auto cur = 0;
+    for (auto& element : obj.elements) {
+      if (element.etype == 'f')
+        for (auto c = 2; c < element.size; c++)
+          shape.triangles.push_back({obj.vertices[(size_t)cur].position - 1, obj.vertices[(size_t)(cur + c - 1)].position - 1, obj.vertices[(size_t)(cur + c)].position - 1});
+      cur += element.size;
+    }
+  }
+  auto cur = 0;
+  for (auto& element : obj.elements) {   // point and line elements: outside the hot-path scope, kept so that flatten rejects the shape
+    if (element.etype != 'f')
+      for (auto c = 0; c < element.size; c++) shape.points.push_back(obj.vertices[(size_t)(cur + c)].position - 1);
+    cur += element.size;
+  }
+  if (shape.points.empty() && shape.triangles.empty() && shape.quads.empty()) {
+    error = filename + ": empty shape";
+    return false;
+  }
+  return true;
+}
+}  // namespace
+
+bool load_shape(const string& filename, shape_data& shape, string& error, bool flip_texcoord) {
+  shape    = {};
+  auto ext = path_extension(filename);
+  if (ext == ".ply") return load_ply_shape(filename, shape, error, flip_texcoord);
+  if (ext == ".obj") return load_obj_shape(filename, shape, error, flip_texcoord);
+  error = filename + ": unknown format";  // STL / ypreset are outside the hot-path scope
+  return false;
+}
+
+// load_subdiv -> load_fvshape(filename, ., ., flip_texcoord = true) (yocto_sceneio.cpp:2829-2840, 1135-1186)
+bool load_subdiv(const string& filename, subdiv_data& subdiv, string& error) {
+  auto ext = path_extension(filename);
+  auto empty_shape = [&]() {
+    error = filename + ": empty shape";
+    return false;
+  };
+  if (ext == ".ply") {   // one index set for all three attributes
+    auto shape = shape_data{};
+    if (!load_ply_shape(filename, shape, error, true)) return false;
+    subdiv.positions = shape.positions, subdiv.normals = shape.normals, subdiv.texcoords = shape.texcoords;
+    subdiv.quadspos = shape.quads;
+    for (auto& t : shape.triangles) subdiv.quadspos.push_back({t.x, t.y, t.z, t.z});
+    subdiv.quadsnorm     = subdiv.normals.empty() ? vector<vec4i>{} : subdiv.quadspos;
+    subdiv.quadstexcoord = subdiv.texcoords.empty() ? vector<vec4i>{} : subdiv.quadspos;
+    if (subdiv.quadspos.empty()) return empty_shape();
+    return true;
+  }
+  if (ext == ".obj") {
+    auto obj = obj_raw{};
+    if (!load_obj_raw(filename, obj, error)) return false;
+    subdiv.positions = obj.positions, subdiv.normals = obj.normals, subdiv.texcoords = obj.texcoords;
+    for (auto& uv : subdiv.texcoords) uv.y = 1 - uv.y;
+    subdiv.quadspos.clear(), subdiv.quadsnorm.clear(), subdiv.quadstexcoord.clear();
+    // get_fvquads (yocto_modelio.cpp:2435-2488): which index kinds exist is decided by the FIRST vertex of the file
+    if (!obj.vertices.empty()) {
+      obj_fan_quads(obj, subdiv.quadspos, [](const obj_vertex& v) { return v.position; });
+      if (obj.vertices[0].normal != 0) obj_fan_quads(obj, subdiv.quadsnorm, [](const obj_vertex& v) { return v.normal; });
+      if (obj.vertices[0].texcoord != 0) obj_fan_quads(obj, subdiv.quadstexcoord, [](const obj_vertex& v) { return v.texcoord; });
+    }
+    if (subdiv.quadspos.empty()) return empty_shape();
+    for (auto& q : subdiv.quadsnorm)   // a later vertex without the index kind the first one had: -1 in the reference, rejected here
+      if (q.x < 0 || q.y < 0 || q.z < 0 || q.w < 0) return empty_shape();
+    for (auto& q : subdiv.quadstexcoord)
+      if (q.x < 0 || q.y < 0 || q.z < 0 || q.w < 0) return empty_shape();
+    return true;
+  }
+  error = filename + ": unknown format";
+  return false;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -666,7 +889,7 @@ bool load_scene(const string& filename, scene_data& scene, string& error) {
     error = filename + ": parse error";
     return false;
   };
-  auto shape_uris = vector<string>{}, texture_uris = vector<string>{}, volume_uris = vector<string>{};
+  auto shape_uris = vector<string>{}, texture_uris = vector<string>{}, volume_uris = vector<string>{}, subdiv_uris = vector<string>{};
   auto volume_binary = vector<bool>{};
   try {
     auto parser = json_parser{(const char*)data.data(), (const char*)data.data() + data.size()};
@@ -736,7 +959,13 @@ bool load_scene(const string& filename, scene_data& scene, string& error) {
         case sdf_type::torus: get_opt(e, "r1", sdf.p[0]), get_opt(e, "r2", sdf.p[1]); break;
       }
     }
-    scene.num_subdivs = (int)group("subdivs").size();
+    for (auto& e : group("subdivs")) {   // yocto_sceneio.cpp:3733-3751
+      auto& subdiv = scene.subdivs.emplace_back();
+      get_opt(e, "uri", subdiv_uris.emplace_back());
+      get_opt(e, "shape", subdiv.shape), get_opt(e, "subdivisions", subdiv.subdivisions);
+      get_opt(e, "catmullclark", subdiv.catmullclark), get_opt(e, "smooth", subdiv.smooth);
+      get_opt(e, "displacement", subdiv.displacement), get_opt(e, "displacement_tex", subdiv.displacement_tex);
+    }
     for (auto& e : group("instances")) {
       auto& instance = scene.instances.emplace_back();
       get_opt(e, "frame", instance.frame), get_opt(e, "shape", instance.shape);
@@ -765,6 +994,8 @@ bool load_scene(const string& filename, scene_data& scene, string& error) {
     if (!load_shape(path_join(dirname, shape_uris[i]), scene.shapes[i], error, true)) return dependent_error();
   for (size_t i = 0; i < scene.volumes.size(); i++)
     if (!load_volume(path_join(dirname, volume_uris[i]), scene.volumes[i], volume_binary[i], error)) return dependent_error();
+  for (size_t i = 0; i < scene.subdivs.size(); i++)
+    if (!load_subdiv(path_join(dirname, subdiv_uris[i]), scene.subdivs[i], error)) return dependent_error();
   for (size_t i = 0; i < scene.textures.size(); i++)
     if (!load_texture(path_join(dirname, texture_uris[i]), scene.textures[i], error)) return dependent_error();
 
@@ -785,6 +1016,9 @@ bool load_scene(const string& filename, scene_data& scene, string& error) {
     if (bad(i.volume, scene.volumes.size(), false) || bad(i.material, scene.materials.size(), false)) return parse_error();
   for (auto& s : scene.sdfs)
     if (bad(s.material, scene.materials.size(), false)) return parse_error();
+  for (auto& s : scene.subdivs)
+    if (bad(s.shape, scene.shapes.size(), false) || bad(s.displacement_tex, scene.textures.size(), true) || s.subdivisions < 0 || s.subdivisions > 10)
+      return parse_error();
   return true;
 }
 

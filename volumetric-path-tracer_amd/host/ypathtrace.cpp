@@ -6,7 +6,8 @@
 // The run itself is the reference's run_offline sequence (:41-87): load, tesselate, bvh, lights, state, N x
 // pathtrace_samples, save.  Rendering happens on the GPU through include/vpt.h; two extensions: --gpus N (tiles dealt
 // round-robin over N GPUs, same image), --batch n (samples per kernel launch; default: all in one, same image) and --gpubvh
-// (the BVHs built on the GPU by vpt_build_bvh: the same trees).
+// (the BVHs built on the GPU by vpt_build_bvh: the same trees), --gputess (the float32 half of tesselate_surfaces on the GPU by
+// vpt_subdivide_vertices: the same meshes).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -39,6 +40,7 @@ const std::vector<std::pair<string, option>> options = {
     {"gpus", {option::int_k, 1, 64, "GPUs to spread the frame's tiles over. (extension)"}},
     {"batch", {option::int_k, 0, 4096, "Samples per kernel launch, 0 = all. (extension)"}},
     {"gpubvh", {option::bool_k, 1, 0, "Build the BVHs on the GPU: same trees. (extension)"}},
+    {"gputess", {option::bool_k, 1, 0, "Subdivision vertex arithmetic on the GPU: same meshes. (extension)"}},
 };
 const option* find_option(const string& name) {
   for (auto& [n, o] : options)
@@ -142,8 +144,8 @@ int main(int argc, const char** argv) {
   get_int("resolution", params.resolution), get_int("samples", params.samples), get_int("bounces", params.bounces);
   get_int("stmaxiter", params.spheretrace_maxiter), get_int("camera", params.camera), get_int("batch", batch), get_int("gpus", gpus);
   get_bool("noparallel", params.noparallel), get_bool("noimplicitmis", params.noimplicit_mis);
-  auto interactive = false, gpubvh = false;
-  get_bool("interactive", interactive), get_bool("gpubvh", gpubvh);
+  auto interactive = false, gpubvh = false, gputess = false;
+  get_bool("interactive", interactive), get_bool("gpubvh", gpubvh), get_bool("gputess", gputess);
   if (interactive) print_fatal("--interactive is not supported by the GPU build");
   if (values.count("shader"))
     for (size_t k = 0; k < pathtrace_shader_names.size(); k++)
@@ -154,7 +156,8 @@ int main(int argc, const char** argv) {
     auto scene = scene_data{};
     if (!load_scene(filename, scene, error)) print_fatal(error);
     if (params.camera >= (int)scene.cameras.size()) cli_error("bad value for camera");
-    tesselate_surfaces(scene);
+    if (gputess) tesselate_surfaces_device(scene, 0);
+    else tesselate_surfaces(scene);
     auto bvh    = gpubvh ? make_bvh_device(scene, params, 0) : make_bvh(scene, params);
     auto lights = make_lights(scene, params);
     auto state  = make_state(scene, params);

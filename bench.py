@@ -251,7 +251,7 @@ class Bench:
         # memory-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs of
         # this same command, profiles/tools/profile_config.sh); only quoted for the workload it was measured on
         tag = {("03_volume", "volpathtrace", 64): "k1", ("05_head1ss_sub", "volpathtrace", 64): "head",
-               ("06_gridsdf_synth", "implicit", 4): "k2"}.get((w.scene_name, w.shader, w.bounces))
+               ("06_gridsdf_full", "implicit", 4): "k2"}.get((w.scene_name, w.shader, w.bounces))
         tfile = profile_file(tag, "hbm_traffic") if tag else None
         if tfile:
             t = json.load(open(tfile))
@@ -374,7 +374,7 @@ def main():
             others = []
             for name, path, shader, bounces, res, spp in (
                     ("config3 (tests/05_head1ss: assets missing, substitute scene)", os.path.join(SCENES, "05_head1ss_sub", "head1ss_sub.json"), "volpathtrace", 64, 1280, 64),
-                    ("config4 (tests/06_gridsdf: assets missing, substitute scene with 96^3 + 64^3 grids)", os.path.join(SCENES, "06_gridsdf_synth", "gridsdf_synth.json"), "implicit", 4, 1280, 128),
+                    ("config4 (tests/06_gridsdf: assets missing, substitute scene with 96^3 + 64^3 grids)", os.path.join(SCENES, "06_gridsdf_full", "gridsdf_full.json"), "implicit", 4, 1280, 128),
                     ("config5's frame on one GPU", SCENE, "volpathtrace", 64, 3840, 64)):
                 wo = B.workload(path, shader, bounces, res, spp)
                 first = B.cold_call(wo)

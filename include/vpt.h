@@ -308,7 +308,7 @@ int vpt_state_download(const vpt_layout* layout, const void* d_image, const void
  * Scheduling: a wave renders all samples of its 64 pixels, so the scene handle remembers how long every
  * wave of the last launch took and starts the next launch on the same layout / camera / shader longest wave
  * first.  Without such a record and with nsamples >= 16, the first nsamples/64 (1..16) samples are rendered by a separate pilot
- * launch that takes the measurement.  Neither changes the result (pixels are independent, batching is exact). */
+ * launch that takes the measurement.  Neither changes the result  (pixels are independent, batching is exact). */
 int vpt_render_device(vpt_scene* scene, const vpt_params* params, const vpt_layout* layout,
                       int nsamples, void* d_image, void* d_hits, void* d_rng, void* stream);
 /* get_render (yocto_pathtrace.cpp:1105-1116) on device: gathered tile-major float4 sums of ALL

@@ -10,12 +10,12 @@ sys.path.insert(0, ROOT)
 import vpt_loader  # noqa: E402
 
 NAMES = ("trips scene_rounds scene_lanes light_rounds light_lanes shade_rounds shade_lanes done_lanes wait_lanes_at_march "
-         "light_lanes_at_scene scene_lanes_at_shade").split()
+         "light_lanes_at_scene scene_lanes_at_shade clk_scene clk_light clk_shade clk_total").split()
 
 
 def main():
     vpt = vpt_loader.load()
-    scene_file = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests/golden/scenes/06_gridsdf_synth/gridsdf_synth.json")
+    scene_file = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests/golden/scenes/06_gridsdf_full/gridsdf_full.json")
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     scene = vpt.HostScene(scene_file)
     dev = vpt.DeviceScene(scene, 0)
@@ -32,6 +32,11 @@ def main():
           f"per shading round {v['shade_lanes'] / max(1, v['shade_rounds']):.1f}")
     print(f"per trip: done lanes {v['done_lanes'] / v['trips']:.1f}, waiting at march trips {v['wait_lanes_at_march'] / max(1, v['trips'] - v['shade_rounds']):.1f}, "
           f"light lanes during scene rounds {v['light_lanes_at_scene'] / max(1, v['scene_rounds']):.1f}, marching lanes parked during shading {v['scene_lanes_at_shade'] / max(1, v['shade_rounds']):.1f}")
+    tot = max(1, v["clk_total"])
+    print(f"wave time (shader clock): scene-march rounds {v['clk_scene'] / tot:.3f}, light-march rounds {v['clk_light'] / tot:.3f}, shading block {v['clk_shade'] / tot:.3f}, "
+          f"rest (prologue, state I/O, loop head) {1 - (v['clk_scene'] + v['clk_light'] + v['clk_shade']) / tot:.3f}")
+    samples = st.width * st.height * spp
+    print(f"per sample: scene rounds {v['scene_rounds'] * 8 / samples * 64:.1f} wave-steps x 64 lanes offered, {v['scene_lanes'] * 8 / samples:.1f} lane-steps used (upper bound: rounds hold up to 8 steps)")
     print(f"rounds: trips {v['trips']}, scene {v['scene_rounds']}, light {v['light_rounds']}, shade {v['shade_rounds']}")
 
 

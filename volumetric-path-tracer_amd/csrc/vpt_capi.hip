@@ -374,6 +374,7 @@ int validate(const vpt_scene_desc& d) {
   for (int i = 0; i < d.num_volumes; i++) {
     const vpt_volume& v = d.volumes[i];
     REQUIRE(v.whd[0] >= 0 && v.whd[1] >= 0 && v.whd[2] >= 0 && v.offset >= 0 && v.offset + (long long)v.whd[0] * v.whd[1] * v.whd[2] <= d.num_voxels, "volume %d: voxels out of range", i);
+    REQUIRE((long long)v.whd[0] * v.whd[1] * v.whd[2] < (1ll << 31), "volume %d: 2^31 voxels or more", i);   // eval_volume indexes a volume with 32-bit arithmetic
   }
   for (int i = 0; i < d.num_vol_instances; i++) {
     REQUIRE(d.vol_instances[i].volume >= 0 && d.vol_instances[i].volume < d.num_volumes, "vol_instance %d: bad volume", i);
@@ -1215,7 +1216,14 @@ static int decide_split(vpt_scene* s, const DParams& pr, int ntiles, int slots, 
 template <int K>
 static int launch_mesh(const launch_ctx& L) {
   vpt_scene* s = L.s;
+#if defined(VPT_EXPERIMENT_ONLY_K2)   // experiment builds (make variant): only the kernels under study are compiled (minutes -> seconds)
+  return fail(VPT_ERR_UNSUPPORTED, "this experiment build holds the implicit kernels only");
+#else
+#if defined(VPT_EXPERIMENT_ONLY_VOLPATH)
+  if (K != K_VOLPATH) return fail(VPT_ERR_UNSUPPORTED, "this experiment build holds the volpathtrace kernel only");
+#else
   if (use_stream_pipeline()) return render_stream<K>(s, L.pr, L.img, L.hit, L.rng, L.st);
+#endif
   long long key[10];
   schedule_key(L, key);
   if (int rc = sched_prepare(s, std::max<long long>(L.grid.x, s->split_waves), key, L.st)) return rc;
@@ -1254,11 +1262,16 @@ static int launch_mesh(const launch_ctx& L) {
     if (int rc = sched_update(s, grid.x, L.st)) return rc;
   }
   return VPT_OK;
+#endif
 }
-// K2 (implicit shaders): same schedule, costs from the previous launch on this layout (no pilot)
+// K2 (implicit shaders): same schedule; without costs of a previous launch on this layout a pilot launch over 1/64 of the call's
+// samples (1..16) measures them first, as for K1 (in tile order a first call ran at 216 against 302 Msamples/s on 06_gridsdf)
 template <int K>
 static int launch_implicit(const launch_ctx& L) {
   vpt_scene* s = L.s;
+#if defined(VPT_EXPERIMENT_ONLY_VOLPATH)
+  return fail(VPT_ERR_UNSUPPORTED, "this experiment build holds the volpathtrace kernel only");
+#else
   long long key[10];
   schedule_key(L, key);
   if (int rc = sched_prepare(s, L.grid.x, key, L.st)) return rc;
@@ -1266,16 +1279,28 @@ static int launch_implicit(const launch_ctx& L) {
   size_t    lds = (size_t)s->stack_cap * VPT_BLOCK * sizeof(int) +                                      // refs-only stack
                (6 * (size_t)s->d.num_sdfs + 7 * (size_t)s->d.num_vol_instances) * sizeof(float4);       // the SDF records
   if (lds > 64 * 1024) return fail(VPT_ERR_UNSUPPORTED, "scene has too many SDFs for the implicit kernel's LDS copy of their records (%d + %d)", s->d.num_sdfs, s->d.num_vol_instances);
-  sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, nullptr};
   s->last_waves = (int)L.grid.x;
   unsigned long long watchdog_ticks = VPT_K2_WATCHDOG_TICKS;
   if (const char* e = getenv("VPT_K2_WATCHDOG_MS")) watchdog_ticks = strtoull(e, nullptr, 10) * 100000ull;   // tests of the error path
   // the instance for the features this scene's lights have (VPT_FEAT_*): SDF scenes without emissive meshes run one without the mesh-light walks
-  if ((s->light_features & (VPT_FEAT_LARGE_LIGHTS | VPT_FEAT_SMALL_LIGHTS)) == 0 && !getenv("VPT_NO_LEAN"))
-    hipLaunchKernelGGL((vpt_render_kernel<K, VPT_FEAT_SDF_LIGHTS>), L.grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog, watchdog_ticks);
-  else
-    hipLaunchKernelGGL((vpt_render_kernel<K, VPT_FEAT_ALL>), L.grid, L.block, lds, L.st, s->d, L.pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog, watchdog_ticks);
-  return sched_update(s, L.grid.x, L.st);
+  const bool lean = (s->light_features & (VPT_FEAT_LARGE_LIGHTS | VPT_FEAT_SMALL_LIGHTS)) == 0 && !getenv("VPT_NO_LEAN");
+  int n = L.pr.nsamples, pilot = n / 64 < 1 ? 1 : n / 64 > 16 ? 16 : n / 64;
+  int parts[2] = {(!s->order_valid && n >= 16 && !getenv("VPT_K2_NO_PILOT")) ? pilot : n, 0};
+  parts[1] = n - parts[0];
+  for (int part = 0; part < 2 && parts[part] > 0; part++) {
+    DParams pr  = L.pr;
+    pr.nsamples = parts[part];
+    const bool is_pilot = parts[1] > 0 && part == 0;
+    sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, nullptr};
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, L.grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog, watchdog_ticks); };
+    if (is_pilot && lean) launch(vpt_render_pilot_kernel<K, VPT_FEAT_SDF_LIGHTS>);
+    else if (is_pilot) launch(vpt_render_pilot_kernel<K, VPT_FEAT_ALL>);
+    else if (lean) launch(vpt_render_kernel<K, VPT_FEAT_SDF_LIGHTS>);
+    else launch(vpt_render_kernel<K, VPT_FEAT_ALL>);
+    if (int rc = sched_update(s, L.grid.x, L.st)) return rc;
+  }
+  return VPT_OK;
+#endif
 }
 
 

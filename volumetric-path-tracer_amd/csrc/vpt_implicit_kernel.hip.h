@@ -34,23 +34,34 @@
 // 1-Lipschitz) still exceeds an upper bound of the scene minimum — exact, five of six SDFs skipped on a floor-grazing
 // march — 166 against 174 Msamples/s: a wave evaluates an SDF as soon as ONE lane needs it, and the table costs more
 // than the few whole-wave skips save (longest wave 388 against 413 ms, but the mean wave 169 against 161 ms).
+// Round 3, also not kept: letting the SDF-light marches ride along in the scene-march rounds (a lane in M_LIGHT evaluates its
+// light's SDF at its own point inside the loop over the analytic SDFs, with the instructions the scene lanes execute anyway).
+// The light rounds (21 % of the wave time at 14 of 64 lanes) disappear, but every scene step then carries the light lanes'
+// bookkeeping (exit tests, receding test, the second set of march registers): 301 against 297 Msamples/s on 06_gridsdf_full, 118
+// against 124 on 07_sdfunction_synth (profiles/r03_k2_experiments.txt).
 #pragma once
 #include "vpt_mesh_kernel.hip.h"
 
 #ifndef VPT_K2_WAVES
-#define VPT_K2_WAVES 4       // waves per SIMD (3: -6 %, 5: -30 %: 102 VGPRs spill the march state)
+#define VPT_K2_WAVES 5       // waves per SIMD (round 3, with the settings below: 4: 324, 5: 341, 6: 284 Msamples/s on 06_gridsdf_full; round 2's kernel lost at 5)
 #endif
 #ifndef VPT_K2_SHADE_AT
-#define VPT_K2_SHADE_AT 24   // lanes waiting for the shading block before the wave runs it (8: -11 %, 16: -4 %, 24: best, 32: -5 %)
+#define VPT_K2_SHADE_AT 20   // lanes waiting for the shading block before the wave runs it (round 2: 8: -11 %, 16: -4 %, 24: best, 32: -5 %; round 3 with the light-march head inline: 16: -3 %, 20: +1 %, 32: -1 %)
 #endif
 #ifndef VPT_K2_WATCHDOG_TICKS
 #define VPT_K2_WATCHDOG_TICKS 30000000000ull   // 300 s: two orders of magnitude above the longest wave of any test workload (the launch passes it as an argument; VPT_K2_WATCHDOG_MS overrides it for the tests of the error path)
 #endif
 #ifndef VPT_K2_LIGHT_INLINE
-#define VPT_K2_LIGHT_INLINE 0   // 1: an SDF light's pdf march runs to its end inside the shading block (measured: 145 against 179 Msamples/s); 0: as M_LIGHT trips of its own
+#define VPT_K2_LIGHT_INLINE 3   // (0: 299, 2: 313, 3: 333, 4: 315-320, 6: 334 Msamples/s on 06_gridsdf_full; 07_sdfunction_synth 121 -> 136) n > 0: the first n steps of an SDF light's pdf march run inside the shading block (55 % of the marches end within two steps: the ray recedes from the light), the rest as M_LIGHT trips; < 0: the whole march inline (round 2: 145 against 179 Msamples/s); 0: all of it as M_LIGHT trips
 #endif
 #ifndef VPT_K2_LIGHT_AT
-#define VPT_K2_LIGHT_AT 8       // (1: 178, 8: 204, 16: 204 Msamples/s) lanes in M_LIGHT before the wave spends a round on light-march steps (while other lanes march the scene)
+#define VPT_K2_LIGHT_AT 4       // lanes in M_LIGHT before the wave spends a round on light-march steps while other lanes march the scene (round 2: 1: 178, 8: 204, 16: 204 Msamples/s; round 3, marches that survive their inline head: 06_gridsdf_full 1: 287, 2: 303, 4: 324, 8: 333; 07_sdfunction_synth 4: 150, 8: 136 - 4 is the better sum)
+#endif
+#ifndef VPT_K2_LIGHT_STEPS
+#define VPT_K2_LIGHT_STEPS 16   // light-march steps per light round (32: 341, 16: 347 Msamples/s)
+#endif
+#ifndef VPT_K2_LIGHT_EXIT
+#define VPT_K2_LIGHT_EXIT 0     // leave a light round as soon as none of its marches is alive
 #endif
 #ifndef VPT_K2_STEPS
 #define VPT_K2_STEPS 8       // march steps between two looks at the wave's state (2: -5 %, 4: -1.5 %, 8: best)
@@ -60,10 +71,15 @@
 #ifdef VPT_K2_STATS
 __device__ unsigned long long g_k2_stats[16];
 enum { KS_TRIPS, KS_SCENE_ROUNDS, KS_SCENE_LANES, KS_LIGHT_ROUNDS, KS_LIGHT_LANES, KS_SHADE_ROUNDS, KS_SHADE_LANES, KS_DONE_LANES,
-  KS_WAIT_LANES_AT_MARCH, KS_LIGHT_LANES_AT_SCENE, KS_SCENE_LANES_AT_SHADE, KS_COUNT };
+  KS_WAIT_LANES_AT_MARCH, KS_LIGHT_LANES_AT_SCENE, KS_SCENE_LANES_AT_SHADE, KS_CLK_SCENE, KS_CLK_LIGHT, KS_CLK_SHADE, KS_CLK_TOTAL, KS_COUNT };
 #define K2_STAT(k, v) stats[k] += (unsigned long long)(v)
+// shader-clock stamp that the scheduler cannot move (diagnostic build only)
+#define K2_CLOCK(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) : : "memory")
+#define K2_LAP(k, a, b) stats[k] += (b) - (a)
 #else
 #define K2_STAT(k, v)
+#define K2_CLOCK(var)
+#define K2_LAP(k, a, b)
 #endif
 
 enum { M_NEW = 0, M_SCENE = 1, M_HIT = 2, M_MISS = 3, M_LIGHT = 4, M_LIGHTS = 5, M_DONE = 6 };
@@ -139,8 +155,8 @@ VPT_DEV float lights_pdf_k2(const DScene& sc, f3 position, f3 direction, int max
 }
 
 template <int SH, int FEAT>
-__global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DScene sc, DParams pr, float4* __restrict__ image,
-    int* __restrict__ hits, ulonglong2* __restrict__ rngs, int stack_cap, sched_cfg sched, unsigned* __restrict__ watchdog, unsigned long long watchdog_ticks) {
+__device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DParams& pr, float4* __restrict__ image,
+    int* __restrict__ hits, ulonglong2* __restrict__ rngs, int stack_cap, const sched_cfg& sched, unsigned* __restrict__ watchdog, unsigned long long watchdog_ticks) {
   extern __shared__ int lds_stack[];
   lane_stack stk;   // binary-node stack: only the pdf walk of an emissive mesh with a real BVH uses it
   stk.base = lds_stack + threadIdx.x;
@@ -193,6 +209,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
 #ifdef VPT_K2_STATS
   unsigned long long stats[KS_COUNT] = {};
 #endif
+  K2_CLOCK(cstart);
   bool gave_up = false;
   while (true) {
     // every wave reaches an exit: the state machine ends when all lanes are M_DONE; should a defect ever keep it from
@@ -210,6 +227,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
     if (marching != 0 && __popcll(waiting) < VPT_K2_SHADE_AT) {
       // ---- march steps ------------------------------------------------------------------------------
       K2_STAT(KS_WAIT_LANES_AT_MARCH, __popcll(waiting));
+      K2_CLOCK(c0);
       if (__builtin_amdgcn_ballot_w64(mode == M_SCENE) != 0) {
         K2_STAT(KS_SCENE_ROUNDS, 1);
         K2_STAT(KS_SCENE_LANES, __popcll(__builtin_amdgcn_ballot_w64(mode == M_SCENE)));
@@ -217,6 +235,8 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
         for (int k = 0; k < VPT_K2_STEPS; k++)
           if (mode == M_SCENE) mode = scene_march_step(sc, recs, ro, rd, maxiter, t, it, hit_instance, hit_sdf);
       }
+      K2_CLOCK(c1);
+      K2_LAP(KS_CLK_SCENE, c0, c1);
       // SDF-light marches: cheap steps (one analytic SDF), several per trip; lanes of one light at a time so that the
       // light's record is wave-uniform (scalar loads)
       unsigned long long lm = __builtin_amdgcn_ballot_w64(mode == M_LIGHT);
@@ -231,13 +251,18 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
         if (mine) {
           const vpt_light& light = sc.lights[l];
           float area = sc.light_cdf[light.cdf_offset + light.cdf_len - 1];
-          for (int k = 0; k < 4 * VPT_K2_STEPS; k++)
+          for (int k = 0; k < VPT_K2_LIGHT_STEPS; k++) {
             if (mode == M_LIGHT && !light_march_step(recs, light.sdf, area, ro, rd, maxiter, lt, lit, lp_sum)) mode = M_LIGHTS, lp_light++;
+            if (VPT_K2_LIGHT_EXIT && __builtin_amdgcn_ballot_w64(mode == M_LIGHT) == 0) break;   // every march of this light has ended
+          }
         }
         lm &= ~__builtin_amdgcn_ballot_w64(mine);
       }
+      K2_CLOCK(c2);
+      K2_LAP(KS_CLK_LIGHT, c1, c2);
       continue;
     }
+    K2_CLOCK(c3);
 
     // ---- shading block: the lanes that wait for it ---------------------------------------------------
     K2_STAT(KS_SHADE_ROUNDS, 1);
@@ -308,14 +333,17 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
           int    kind = __float_as_int(r7.w) & 255;
           if (kind == VPT_LIGHT_SDF) {
             lt = VPT_RAY_EPS, lit = 0;
-            if (VPT_K2_LIGHT_INLINE) {   // experiment: see the macro
+            if (VPT_K2_LIGHT_INLINE != 0) {   // the march's first steps (all of them if < 0) here, in the shading block
               const vpt_light& light = sc.lights[lp_light];
               float area = sc.light_cdf[light.cdf_offset + light.cdf_len - 1];
-              while (light_march_step(recs, light.sdf, area, ro, rd, maxiter, lt, lit, lp_sum)) {}
-              lp_light++;
-              continue;
+              bool  alive = true;
+              for (int k = 0; alive && (VPT_K2_LIGHT_INLINE < 0 || k < VPT_K2_LIGHT_INLINE); k++) alive = light_march_step(recs, light.sdf, area, ro, rd, maxiter, lt, lit, lp_sum);
+              if (!alive) {
+                lp_light++;
+                continue;
+              }
             }
-            mode = M_LIGHT;   // needs a march: hand over
+            mode = M_LIGHT;   // needs (the rest of) a march: hand over
             break;
           }
           lp_sum += inline_light_pdf<FEAT>(sc, lp_light, kind, r6, r7, ro, rd, stk);
@@ -362,6 +390,8 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
         if (SH == K_IMPLICIT && nb <= 0) mode = M_MISS, weight = mk3(0, 0, 0);   // no bounce allowed: the reference's loop body never runs (radiance 0, alpha 1)
       }
     }
+    K2_CLOCK(c4);
+    K2_LAP(KS_CLK_SHADE, c3, c4);
   }
 
   if (gave_up && threadIdx.x == 0 && watchdog) atomicAdd(watchdog, 1u);
@@ -373,6 +403,8 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
     rngs[slot] = r_out;
   }
 #ifdef VPT_K2_STATS
+  K2_CLOCK(cend);
+  K2_LAP(KS_CLK_TOTAL, cstart, cend);
   if (threadIdx.x == 0)
     for (int k = 0; k < KS_COUNT; k++) atomicAdd(&g_k2_stats[k], stats[k]);
 #endif
@@ -380,4 +412,17 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DSc
     unsigned long long dt = clock_ticks(__float_as_int(acc.x)) - wave_start;   // after the last sample was accumulated
     sched.cost[wave] = dt < 0xffffffffull ? (unsigned)dt : 0xffffffffu;
   }
+}
+
+template <int SH, int FEAT>
+__global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_kernel(DScene sc, DParams pr, float4* __restrict__ image,
+    int* __restrict__ hits, ulonglong2* __restrict__ rngs, int stack_cap, sched_cfg sched, unsigned* __restrict__ watchdog, unsigned long long watchdog_ticks) {
+  implicit_kernel_body<SH, FEAT>(sc, pr, image, hits, rngs, stack_cap, sched, watchdog, watchdog_ticks);
+}
+// The same kernel under another name: the short launch that measures per-wave costs when none are known yet (vpt_capi.hip),
+// kept apart so that profiles of vpt_render_kernel only hold full launches (as vpt_mesh_pilot_kernel for K1).
+template <int SH, int FEAT>
+__global__ void __launch_bounds__(VPT_BLOCK, VPT_K2_WAVES) vpt_render_pilot_kernel(DScene sc, DParams pr, float4* __restrict__ image,
+    int* __restrict__ hits, ulonglong2* __restrict__ rngs, int stack_cap, sched_cfg sched, unsigned* __restrict__ watchdog, unsigned long long watchdog_ticks) {
+  implicit_kernel_body<SH, FEAT>(sc, pr, image, hits, rngs, stack_cap, sched, watchdog, watchdog_ticks);
 }

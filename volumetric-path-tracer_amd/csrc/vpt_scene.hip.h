@@ -902,6 +902,9 @@ VPT_DEV float sd_capped_cone(f3 p, float h, float r1, float r2) {
 // Where the records are read from: the scene's tables in HBM (DScene::sdf_fn_rec / sdf_grid_rec), or a copy a kernel made
 // in its LDS (K2: the records are wave-uniform and read six times per march step; from HBM each read is a vector load
 // with its full latency on the critical path of the step, from LDS a broadcast ds_read).
+#ifndef VPT_SDF_PREFETCH
+#define VPT_SDF_PREFETCH 0   // eval_sdf_scene fetches the next voxel-grid record while it evaluates the current one
+#endif
 struct sdf_recs { const float4 *fn, *grid; };
 VPT_DEV sdf_recs scene_sdf_recs(const DScene& sc) { sdf_recs r = {sc.sdf_fn_rec, sc.sdf_grid_rec}; return r; }
 VPT_DEV f3 sdf_to_local(const float4* rec, bool translation, f3 pw) {
@@ -926,10 +929,11 @@ VPT_DEV float sdf_fn_world(const sdf_recs& recs, int idx, f3 pw) {   // sdf.f(tr
   const float4* rec = recs.fn + 6 * idx;
   return sdf_fn_local(rec, sdf_to_local(rec, (__float_as_int(rec[4].w) >> 8) & 1, pw));
 }
-// eval_volume: 8-tap trilinear in the reference's term order, yocto_sdfs.cpp:92-127
+// eval_volume: 8-tap trilinear in the reference's term order, yocto_sdfs.cpp:92-127.  A volume holds fewer than 2^31 voxels
+// (checked at vpt_scene_create), so the eight indices are 32-bit arithmetic on top of one 64-bit base.
 VPT_DEV float eval_volume(const DScene& sc, const vpt_volume& vol, f3 uvw) {
   int W = vol.whd[0], H = vol.whd[1], D = vol.whd[2];
-  if ((long long)W * H * D == 0) return 0;
+  if (W == 0 || H == 0 || D == 0) return 0;
   float s = clampf((uvw.x + 1.0f) * 0.5f, 0.0f, 1.0f) * (W - 1);
   float t = clampf((uvw.y + 1.0f) * 0.5f, 0.0f, 1.0f) * (H - 1);
   float r = clampf((uvw.z + 1.0f) * 0.5f, 0.0f, 1.0f) * (D - 1);
@@ -937,23 +941,23 @@ VPT_DEV float eval_volume(const DScene& sc, const vpt_volume& vol, f3 uvw) {
   int ii = min(i + 1, W - 1), jj = min(j + 1, H - 1), kk = min(k + 1, D - 1);
   float u = s - i, v = t - j, w = r - k;
   const float* vox = sc.voxels + vol.offset;
-  long long WH = (long long)W * H;
-  float v000 = vox[i + (long long)j * W + k * WH], v100 = vox[ii + (long long)j * W + k * WH];
-  float v010 = vox[i + (long long)jj * W + k * WH], v001 = vox[i + (long long)j * W + kk * WH];
-  float v011 = vox[i + (long long)jj * W + kk * WH], v101 = vox[ii + (long long)j * W + kk * WH];
-  float v110 = vox[ii + (long long)jj * W + k * WH], v111 = vox[ii + (long long)jj * W + kk * WH];
+  const int WH = W * H, r0 = j * W + k * WH, r1 = jj * W + k * WH, r2 = j * W + kk * WH, r3 = jj * W + kk * WH;
+  float v000 = vox[i + r0], v100 = vox[ii + r0];
+  float v010 = vox[i + r1], v001 = vox[i + r2];
+  float v011 = vox[i + r3], v101 = vox[ii + r2];
+  float v110 = vox[ii + r1], v111 = vox[ii + r3];
   return v000 * (1 - u) * (1 - v) * (1 - w) + v100 * u * (1 - v) * (1 - w) + v010 * (1 - u) * v * (1 - w) +
          v001 * (1 - u) * (1 - v) * w + v011 * (1 - u) * v * w + v101 * u * (1 - v) * w + v110 * u * v * (1 - w) +
          v111 * u * v * w;
 }
-// eval_sdf(volume, instance, p_local, t) behind the instance's transform, yocto_sdfs.cpp:13 + 30-49
-VPT_DEV float sdf_grid_world(const DScene& sc, const sdf_recs& recs, int idx, f3 pw, float t) {
-  const float4* rec = recs.grid + 7 * idx;
-  float4 sz = rec[3], hf = rec[4];
-  f3     p  = sdf_to_local(rec, __float_as_int(hf.w) & 1, pw);
+// eval_sdf(volume, instance, p_local, t) behind the instance's transform, yocto_sdfs.cpp:13 + 30-49.  r2 / hf: the record's
+// words [2] and [4] (translation, half box size | translation flag), handed in so that a caller walking over the records can
+// fetch the next instance's while this one is evaluated (they come from LDS: ~100 cycles that nothing else would cover)
+VPT_DEV float sdf_grid_world(const DScene& sc, const float4* rec, float4 r2, float4 hf, f3 pw, float t) {
+  f3 p = (__float_as_int(hf.w) & 1) ? mk3(pw.x + r2.y, pw.y + r2.z, pw.z + r2.w) : transform_point(unpack_frame(rec[0], rec[1], r2), pw);
   float  bbox_dist = sd_box(p - xyz(hf), xyz(hf));
   if (bbox_dist < VPT_FLT_EPS * t) {
-    float4 g = rec[5], o = rec[6];
+    float4 sz = rec[3], g = rec[5], o = rec[6];
     vpt_volume vol;
     vol.whd[0] = __float_as_int(g.x), vol.whd[1] = __float_as_int(g.y), vol.whd[2] = __float_as_int(g.z), vol.res = g.w;
     vol.offset = (long long)(unsigned)__float_as_int(o.x) | ((long long)__float_as_int(o.y) << 32);
@@ -962,13 +966,30 @@ VPT_DEV float sdf_grid_world(const DScene& sc, const sdf_recs& recs, int idx, f3
   }
   return bbox_dist;
 }
+VPT_DEV float sdf_grid_world(const DScene& sc, const sdf_recs& recs, int idx, f3 pw, float t) {
+  const float4* rec = recs.grid + 7 * idx;
+  return sdf_grid_world(sc, rec, rec[2], rec[4], pw, t);
+}
 struct sdf_hit { float result; int instance, sdf; };
 VPT_DEV sdf_hit eval_sdf_scene(const DScene& sc, const sdf_recs& recs, f3 p, float t) {   // yocto_sdfs.cpp:7-26 (first minimum wins ties)
   sdf_hit res = {VPT_FLT_MAX, -1, -1};
+#if VPT_SDF_PREFETCH
+  const int nvol = sc.num_vol_instances;
+  float4 r2 = make_float4(0, 0, 0, 0), hf = r2;
+  if (nvol > 0) r2 = recs.grid[2], hf = recs.grid[4];
+  for (int idx = 0; idx < nvol; idx++) {
+    const float4* rec = recs.grid + 7 * idx;
+    const float4 r2c = r2, hfc = hf;
+    if (idx + 1 < nvol) r2 = rec[7 + 2], hf = rec[7 + 4];   // the next instance's words, in flight during this evaluation
+    float d = sdf_grid_world(sc, rec, r2c, hfc, p, t);
+    if (d < res.result) res.result = d, res.instance = idx, res.sdf = -1;
+  }
+#else
   for (int idx = 0; idx < sc.num_vol_instances; idx++) {
     float d = sdf_grid_world(sc, recs, idx, p, t);
     if (d < res.result) res.result = d, res.instance = idx, res.sdf = -1;
   }
+#endif
   for (int idx = 0; idx < sc.num_sdfs; idx++) {
     float d = sdf_fn_world(recs, idx, p);
     if (d < res.result) res.result = d, res.instance = -1, res.sdf = idx;

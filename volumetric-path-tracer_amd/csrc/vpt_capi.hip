@@ -1248,15 +1248,25 @@ static int launch_mesh(const launch_ctx& L) {
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, L.stack, sch); };
     auto launch_feat = [&](auto feat) {
       constexpr int F = decltype(feat)::value;
+#if defined(VPT_EXPERIMENT_ONLY_VOLPATH)   // experiment builds: the pilot runs the same instance (one kernel less to compile)
+      if (L.stack.spill) launch(vpt_mesh_kernel<K, true, F>);
+      else launch(vpt_mesh_kernel<K, false, F>);
+#else
       if (is_pilot && L.stack.spill) launch(vpt_mesh_pilot_kernel<K, true, F>);
       else if (is_pilot) launch(vpt_mesh_pilot_kernel<K, false, F>);
       else if (L.stack.spill) launch(vpt_mesh_kernel<K, true, F>);
       else launch(vpt_mesh_kernel<K, false, F>);
+#endif
     };
     // three instances: single-leaf mesh lights only / + emissive meshes with a BVH / everything (SDF lights too)
+#if defined(VPT_EXPERIMENT_ONLY_VOLPATH)
+    if (need != VPT_FEAT_SMALL_LIGHTS && (need & (VPT_FEAT_LARGE_LIGHTS | VPT_FEAT_SDF_LIGHTS)) != 0) return fail(VPT_ERR_UNSUPPORTED, "this experiment build holds the lean instance only");
+    launch_feat(std::integral_constant<int, VPT_FEAT_SMALL_LIGHTS>{});
+#else
     if ((need & (VPT_FEAT_LARGE_LIGHTS | VPT_FEAT_SDF_LIGHTS)) == 0) launch_feat(std::integral_constant<int, VPT_FEAT_SMALL_LIGHTS>{});
     else if ((need & VPT_FEAT_SDF_LIGHTS) == 0) launch_feat(std::integral_constant<int, VPT_FEAT_SMALL_LIGHTS | VPT_FEAT_LARGE_LIGHTS>{});
     else launch_feat(std::integral_constant<int, VPT_FEAT_ALL>{});
+#endif
     if (s->split_waves == 0) s->full_costs = pr.nsamples >= 8;   // d_cost now holds per-tile durations over enough samples (a pilot of a call with >= 512 samples counts)
     s->last_waves = (int)grid.x;
     if (int rc = sched_update(s, grid.x, L.st)) return rc;

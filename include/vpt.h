@@ -303,7 +303,9 @@ int vpt_state_upload(const vpt_layout* layout, const float* image_rgba, const in
 int vpt_state_download(const vpt_layout* layout, const void* d_image, const void* d_hits,
                        const void* d_rng, float* image_rgba, int32_t* hits, uint64_t* rng,
                        void* stream);
-/* nsamples passes over this rank's pixels; asynchronous on `stream` (hipStream_t).  params->samples == 1
+/* nsamples passes over this rank's pixels; asynchronous on `stream` (hipStream_t) - with one exception per layout: the call
+ * that takes the tile-splitting decision (below: the second full call on a layout that is short of waves) waits for the previous
+ * launch and reads its per-tile costs back (a few tens of ms at 3840x1600) before it enqueues.  params->samples == 1
  * selects the pixel-centre preview branch (yocto_pathtrace.cpp:1059-1068).
  * Scheduling: a wave renders all samples of its 64 pixels, so the scene handle remembers how long every
  * wave of the last launch took and starts the next launch on the same layout / camera / shader longest wave

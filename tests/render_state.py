@@ -1,5 +1,5 @@
-"""Helper for test_gpu_parity.py: render one configuration in a fresh process (the pipeline choice VPT_PIPELINE
-is read once per process) and save the resulting pathtrace_state.
+"""Helper for the GPU tests: render one configuration in a fresh process (build switches such as VPT_NO_LEAN / VPT_HIP_LIB are
+read once per process) and save the resulting pathtrace_state.
 
   python render_state.py <scene.json> <shader> <resolution> <spp> <bounces> <out.npz>
 """

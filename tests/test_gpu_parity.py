@@ -302,31 +302,6 @@ def test_reciprocal_shortcut_is_exact_for_every_float(vpt):
     assert skipped == 2 * 6 * (1 << 23)
 
 
-@pytest.mark.parametrize("scene_file,shader,res,spp,bounces", [
-    ("03_volume/volume.json", "volpathtrace", 96, 4, 64),
-    ("05_head1ss_sub/head1ss_sub.json", "volpathtrace", 64, 2, 16),   # BVH deep enough for the HBM-backed stack variant
-    ("01_surface_min/surface_min.json", "pathtrace", 96, 4, 8),
-])
-def test_streaming_pipeline_is_bit_identical(vpt, tmp_path, scene_file, shader, res, spp, bounces):
-    """VPT_PIPELINE=stream (k_begin / k_trace / k_shade over ray queues) must end in exactly the state the
-    single-kernel form produces: same arithmetic, same per-pixel draw order, only the schedule differs."""
-    import subprocess
-    import sys
-    path = os.path.join(GOLDEN, "scenes", scene_file)
-    out = str(tmp_path / "stream.npz")
-    env = dict(os.environ, VPT_PIPELINE="stream")
-    subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "render_state.py"), path, shader, str(res), str(spp),
-                    str(bounces), out], check=True, env=env, timeout=300)
-    got = np.load(out)
-    scene = vpt.HostScene(path)
-    dev = vpt.DeviceScene(scene, 0)
-    p = vpt.PathtraceParams(resolution=res, samples=spp, shader=shader, bounces=bounces)
-    st = scene.make_state(p)
-    dev.pathtrace_samples(st, p, spp)
-    assert np.array_equal(got["rngs"], st.rngs) and np.array_equal(got["hits"], st.hits)
-    assert np.array_equal(got["image"].view(np.uint32), st.image.view(np.uint32))
-
-
 @pytest.mark.parametrize("scene_file", ["03_volume/volume.json", "05_head1ss_sub/head1ss_sub.json"])
 def test_light_cdf_index_equals_upper_bound(vpt, scene_file):
     """The guide table + 16-ary levels over a large light CDF must return std::upper_bound's index for CDF

@@ -52,7 +52,8 @@ def test_adaptive_split_of_a_shared_frame_gives_the_same_state(tmp_path):
     assert auto["waves"][0] == tiles and auto["waves"][1] > tiles and auto["waves"][2] == auto["waves"][1]
     assert _same_state(base, auto)
     print("rank 3 of 8, 1280x533x32spp: unsplit", base["ms"], "ms; split", auto["ms"], "ms;", int(auto["waves"][1]), "waves for", tiles, "tiles")
-    assert auto["ms"][2] < 0.85 * base["ms"][2]     # measured on MI355X: ~0.6
+    # timing is printed, not asserted (one run each on a shared GPU: a correctness test must not depend on the clock); measured on
+    # MI355X the split launch takes ~0.6 of the unsplit one (profiles/r02_strong_scaling_rehearsal.txt holds the measured series)
 
 
 def test_a_full_size_frame_on_one_gpu_is_left_alone(tmp_path):
@@ -69,4 +70,4 @@ def test_a_small_frame_on_one_gpu_is_split_and_unchanged(tmp_path):
     assert list(base["waves"]) == [tiles] * 3 and auto["waves"][0] == tiles and auto["waves"][2] > tiles
     assert _same_state(base, auto)
     print("720x300x32spp on one GPU: unsplit", base["ms"], "ms; split", auto["ms"], "ms")
-    assert auto["ms"][2] < 0.9 * base["ms"][2]     # measured on MI355X at 256 spp: 212 -> 152 ms
+    # (timing printed, not asserted; measured on MI355X at 256 spp: 212 -> 152 ms, profiles/r02_small_frames_tile_splitting.txt)

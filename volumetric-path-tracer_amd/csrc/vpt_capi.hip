@@ -15,7 +15,6 @@
 #include <string>
 #include <vector>
 
-#include "vpt_stream_kernels.hip.h"
 #include "vpt_implicit_kernel.hip.h"
 #include "vpt_kat_kernels.hip.h"
 #include <rocprim/rocprim.hpp>
@@ -230,7 +229,7 @@ struct vpt_scene {
   int                device = 0;
   DScene             d      = {};
   std::vector<void*> allocs;
-  int                stack_cap = 16;    // binary-BVH kernels (implicit shaders, stream k_shade): refs only
+  int                stack_cap = 16;    // binary-BVH walk of the implicit kernels' mesh-light pdf: refs only
   int                stack_lds4 = 8, stack_spill4 = 0;   // quad-node traversal: (ref, t0) entries in LDS / in HBM
   void*              spill = nullptr;
   long long          spill_lanes = 0;
@@ -261,15 +260,8 @@ struct vpt_scene {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool       timed = false;
   unsigned*  d_watchdog = nullptr;   // waves of the implicit kernel that gave up (must stay 0; vpt_implicit_kernel.hip.h)
-  // streaming pipeline (vpt_stream_kernels.hip.h): path state + ray queues, sized for `path_slots`
-  DPaths     paths = {};
-  long long  path_slots = 0;
-  std::vector<void*> path_allocs;
-  int*       host_counts = nullptr;   // pinned, 2 ints
   bool       large_mesh_lights = false;
   int        light_features = 0;      // VPT_FEAT_* bits this scene's lights need from the mesh kernels
-  long long  last_iterations = 0;
-  int        trace_blocks = 1024;     // resident workgroups of the persistent trace kernel
   // host mirrors of a few index tables: range checks of the batch entry points (vpt_intersect, vpt_kat)
   std::vector<int> h_slot_of;                          // instance -> scene-BVH primitive slot (-1: not in the scene BVH)
   std::vector<int> h_inst_shape, h_shape_elems, h_shape_elem_offset;
@@ -447,12 +439,10 @@ void vpt_scene_destroy(vpt_scene* s) {
   for (void* p : s->allocs) (void)hipFree(p);
   for (void* p : {s->s_image, s->s_hits, s->s_rng, s->r_image, s->r_hits, s->r_rng})
     if (p) (void)hipFree(p);
-  for (void* p : s->path_allocs) (void)hipFree(p);
   if (s->spill) (void)hipFree(s->spill);
   for (void* p : {(void*)s->d_cost, (void*)s->d_cost_sorted, (void*)s->d_order, (void*)s->d_iota, s->sort_temp, (void*)s->d_lane_slot})
     if (p) (void)hipFree(p);
   if (s->ev_order) (void)hipEventDestroy(s->ev_order);
-  if (s->host_counts) (void)hipHostFree(s->host_counts);
   if (s->d_watchdog) (void)hipFree(s->d_watchdog);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -844,11 +834,6 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
-    size_t lds_block = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int);
-    int per_cu = (int)((160 * 1024) / (lds_block ? lds_block : 1));
-    if (per_cu > 4) per_cu = 4;   // __launch_bounds__(256, 4): 4 waves/SIMD = 4 workgroups/CU
-    if (per_cu < 1) per_cu = 1;
-    s->trace_blocks = prop.multiProcessorCount * per_cu;
     s->wave_slots_k1 = prop.multiProcessorCount * 4 * VPT_WAVES_PER_SIMD;
   }
   if (d.num_lights > 0) {   // element normals of the single-leaf mesh lights, by the device's own eval_element_normal
@@ -952,28 +937,6 @@ int vpt_state_download(const vpt_layout* layout, const void* d_image, const void
 
 }  // extern "C"
 
-static int ensure_paths(vpt_scene* s, long long nslots) {
-  if (s->path_slots == nslots) return VPT_OK;
-  for (void* p : s->path_allocs) (void)hipFree(p);
-  s->path_allocs.clear();
-  s->path_slots = 0;
-  auto alloc = [&](size_t bytes, void** out) -> int {
-    HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
-    s->path_allocs.push_back(*out);
-    return VPT_OK;
-  };
-  size_t n = (size_t)nslots;
-  DPaths& P = s->paths;
-  int rc;
-#define PA(field, bytes) if ((rc = alloc((bytes), (void**)&P.field)) != VPT_OK) return rc
-  PA(ray_o, n * 16); PA(ray_d, n * 16); PA(weight, n * 16); PA(rad, n * 16); PA(med0, n * 16); PA(med1, n * 16);
-  PA(med2, n * 8); PA(hit, n * 16); PA(hit_t, n * 4); PA(queue[0], n * 4); PA(queue[1], n * 4); PA(count, 16);
-#undef PA
-  if (!s->host_counts) HIP_TRY(hipHostMalloc((void**)&s->host_counts, 16, hipHostMallocDefault));
-  s->path_slots = nslots;
-  return VPT_OK;
-}
-
 // HBM part of the traversal stacks for a launch of `lanes` lanes (only scenes whose worst case exceeds the LDS part)
 static int stack_config(vpt_scene* s, long long lanes, stack_cfg& cfg) {
   if (s->stack_spill4 > 0 && lanes > s->spill_lanes) {
@@ -1022,48 +985,6 @@ static int sched_update(vpt_scene* s, long long waves, hipStream_t st) {
 static int sched_wait(vpt_scene* s, hipStream_t st) {
   if (s->order_valid && s->order_stream != st) HIP_TRY(hipStreamWaitEvent(st, s->ev_order, 0));
   return VPT_OK;
-}
-
-// The streaming form of K1: k_begin, then (k_trace, k_shade) pairs until every queue is empty.
-// Queue sizes only shrink, so the grid follows the last count read back (every 16 iterations).
-template <int K>
-static int render_stream(vpt_scene* s, const DParams& pr, float4* img, int* hit, ulonglong2* rng, hipStream_t st) {
-  if (int rc = ensure_paths(s, pr.nslots)) return rc;
-  const DPaths& P = s->paths;
-  size_t lds_trace = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int);
-  stack_cfg stack;
-  if (int rc = stack_config(s, ((long long)pr.nslots + VPT_BLOCK - 1) / VPT_BLOCK * VPT_BLOCK, stack)) return rc;
-  size_t lds_shade = s->large_mesh_lights ? (size_t)s->stack_cap * VPT_BLOCK * sizeof(int) : 0;
-  HIP_TRY(hipMemsetAsync(P.count, 0, 16, st));
-  int blocks = (pr.nslots + VPT_BLOCK - 1) / VPT_BLOCK;
-  hipLaunchKernelGGL(vpt_stream_begin<K>, dim3(blocks), dim3(VPT_BLOCK), 0, st, s->d, pr, P, img, hit, rng);
-  HIP_TRY(hipGetLastError());
-  int q = 0;
-  long long upper = pr.nslots, it = 0;
-  while (upper > 0) {
-    int grid = (int)((upper + VPT_BLOCK - 1) / VPT_BLOCK);
-    if (stack.spill) hipLaunchKernelGGL(vpt_stream_trace<true>, dim3(grid), dim3(VPT_BLOCK), lds_trace, st, s->d, P, q, stack);
-    else hipLaunchKernelGGL(vpt_stream_trace<false>, dim3(grid), dim3(VPT_BLOCK), lds_trace, st, s->d, P, q, stack);
-    hipLaunchKernelGGL(vpt_stream_shade<K>, dim3(grid), dim3(VPT_BLOCK), lds_shade, st, s->d, pr, P, q, img, hit, rng, s->stack_cap);
-    q ^= 1;
-    if ((++it & 15) == 0) {
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(s->host_counts, P.count, 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      upper = s->host_counts[q];
-    }
-    if (it > (1LL << 24)) return fail(VPT_ERR_HIP, "streaming pipeline did not terminate");
-  }
-  s->last_iterations = it;
-  return VPT_OK;
-}
-
-static bool use_stream_pipeline() {
-  static int choice = [] {
-    const char* e = getenv("VPT_PIPELINE");
-    return (e && !strcmp(e, "stream")) ? 1 : 0;   // default: the single-kernel form (faster on MI355X)
-  }();
-  return choice != 0;
 }
 
 // everything one vpt_render_device call hands to the kernel launchers
@@ -1221,8 +1142,6 @@ static int launch_mesh(const launch_ctx& L) {
 #else
 #if defined(VPT_EXPERIMENT_ONLY_VOLPATH)
   if (K != K_VOLPATH) return fail(VPT_ERR_UNSUPPORTED, "this experiment build holds the volpathtrace kernel only");
-#else
-  if (use_stream_pipeline()) return render_stream<K>(s, L.pr, L.img, L.hit, L.rng, L.st);
 #endif
   long long key[10];
   schedule_key(L, key);
@@ -1239,8 +1158,10 @@ static int launch_mesh(const launch_ctx& L) {
     pr.nsamples = parts[part];
     bool is_pilot = parts[1] > 0 && part == 0;
     // the costs of an unsplit launch over at least 8 samples decide, once, whether tiles are split from now on
-    if (may_split && !s->split_decided && s->order_valid && s->full_costs)
+    if (may_split && !s->split_decided && s->order_valid && s->full_costs) {
       if (int rc = decide_split(s, pr, (int)L.grid.x, s->wave_slots_k1, L.st)) return rc;
+      HIP_TRY(hipEventRecord(s->ev0, L.st));   // the decision waited for the stream and read costs back on the host: not kernel time (vpt_last_kernel_ms)
+    }
     dim3 grid = s->split_waves > 0 ? dim3((unsigned)s->split_waves) : L.grid;
     sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, s->split_waves > 0 ? s->d_lane_slot : nullptr};
     // the instance compiled for the features this scene has (vpt_scene.hip.h: VPT_FEAT_*)

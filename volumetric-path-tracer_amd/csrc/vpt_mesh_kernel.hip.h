@@ -433,8 +433,7 @@ VPT_DEV float other_light_pdf(const DScene& sc, int light_id, int kind, float4 r
 }
 
 // sample_lights_pdf's mesh-light walk (yocto_pathtrace.cpp:359-380) for an emissive mesh with a real BVH;
-// binary-node form with a refs-only LDS stack, for the kernels that do not carry the quad-node traversal (K2, the
-// stream pipeline's shade kernel)
+// binary-node form with a refs-only LDS stack, for the kernel that does not carry the quad-node traversal (K2)
 VPT_DEV float general_light_pdf(const DScene& sc, const vpt_light& light, f3 position, f3 direction, const lane_stack& stk) {
   const DInstance& inst = sc.instances[light.instance];
   float area = sc.light_cdf[light.cdf_offset + light.cdf_len - 1];

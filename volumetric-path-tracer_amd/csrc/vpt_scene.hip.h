@@ -1,5 +1,5 @@
-// vpt_scene.hip.h — device functions: primitive tests, the binary-node shape traversal behind K2's and the
-// stream pipeline's mesh-light pdf walk (K1 walks quad nodes: traverse(), vpt_mesh_kernel.hip.h),
+// vpt_scene.hip.h — device functions: primitive tests, the binary-node shape traversal behind K2's
+// mesh-light pdf walk (K1 walks quad nodes: traverse(), vpt_mesh_kernel.hip.h),
 // scene/material/texture/environment evaluation, BSDF lobes, media, light sampling, SDF sphere
 // tracing.  Each function names the reference lines whose arithmetic it reproduces
 // (libs/yocto/*.h|cpp, libs/yocto_pathtrace/yocto_pathtrace.cpp).

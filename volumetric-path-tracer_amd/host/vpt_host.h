@@ -203,7 +203,11 @@ void pathtrace_samples(pathtrace_state& state, const scene_data& scene, const bv
 // Extension: `count` consecutive calls in one launch batch (same result).
 void pathtrace_samples(pathtrace_state& state, const scene_data& scene, const bvh_scene& bvh,
     const pathtrace_lights& lights, const pathtrace_params& params, int count);
-void pathtrace_release(const scene_data& scene);  // drop the cached device copy of `scene`
+// Drop the cached device copy of `scene`.  pathtrace_samples notices by itself a scene rebuilt at the same address and every
+// in-place edit of the small tables (cameras, instances, materials, environments, volume instances, SDFs, lights: hashed in full
+// on each call); in-place edits of BULK data - vertex arrays, texels, voxels, BVH nodes, light CDFs - are only sampled at head
+// and tail and have to be announced with this call.
+void pathtrace_release(const scene_data& scene);
 // Extension: the GPUs pathtrace_samples renders on (default {0}).  With more than one, the frame's 8x8 tiles are dealt
 // round-robin to them (vpt_multi of include/vpt.h); the result does not depend on the list.  Drops the cached copies.
 void pathtrace_set_devices(const vector<int>& devices);

@@ -427,7 +427,7 @@ vector<int>& device_list() {
 }
 uint64_t mix(uint64_t h, uint64_t v) { return (h ^ v) * 0x100000001b3ull; }
 template <typename T>
-uint64_t mix_array(uint64_t h, const vector<T>& v) {
+uint64_t mix_array(uint64_t h, const vector<T>& v) {   // bulk arrays: address, size, head and tail
   h = mix(mix(h, (uint64_t)(uintptr_t)v.data()), v.size());
   auto bytes = (const unsigned char*)v.data();
   auto n     = v.size() * sizeof(T);
@@ -435,10 +435,29 @@ uint64_t mix_array(uint64_t h, const vector<T>& v) {
   for (size_t i = n > 256 ? n - 256 : n; i < n; i++) h = mix(h, bytes[i]);  // tail
   return h;
 }
+template <typename T>
+uint64_t mix_table(uint64_t h, const vector<T>& v) {   // small tables (a few KB): every byte, eight at a time
+  h = mix(mix(h, (uint64_t)(uintptr_t)v.data()), v.size());
+  auto bytes = (const unsigned char*)v.data();
+  auto n     = v.size() * sizeof(T);
+  auto i     = (size_t)0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    memcpy(&w, bytes + i, 8);
+    h = mix(h, w);
+  }
+  for (; i < n; i++) h = mix(h, bytes[i]);
+  return h;
+}
+// What the cached device copy was made from.  The small tables - cameras, instances, materials, environments, volume
+// instances, SDFs, light ids - are hashed in full, so an in-place edit of any of them (a moved instance, a changed material or
+// camera) rebuilds the copy on the next call, as the reference - which reads the live scene - would show it.  The bulk arrays
+// (vertex data, texels, voxels, BVH nodes, light CDFs) are sampled at head and tail only: editing them in place between two calls
+// needs pathtrace_release(scene) (vpt_host.h).
 uint64_t scene_fingerprint(const scene_data& scene, const bvh_scene& bvh, const pathtrace_lights& lights) {
   auto h = 0xcbf29ce484222325ull;
-  h = mix_array(h, scene.cameras), h = mix_array(h, scene.instances), h = mix_array(h, scene.materials);
-  h = mix_array(h, scene.environments), h = mix_array(h, scene.vol_instances), h = mix_array(h, scene.sdfs);
+  h = mix_table(h, scene.cameras), h = mix_table(h, scene.instances), h = mix_table(h, scene.materials);
+  h = mix_table(h, scene.environments), h = mix_table(h, scene.vol_instances), h = mix_table(h, scene.sdfs);
   h = mix(h, scene.shapes.size()), h = mix(h, scene.textures.size()), h = mix(h, scene.volumes.size());
   for (auto& s : scene.shapes) h = mix_array(h, s.positions), h = mix(h, s.triangles.size()), h = mix(h, s.quads.size());
   for (auto& t : scene.textures) h = mix(mix(h, (uint64_t)t.width), (uint64_t)t.height), h = mix_array(h, t.pixelsb), h = mix_array(h, t.pixelsf);

@@ -153,3 +153,70 @@ def test_device_levels_equal_host_levels_bit_for_bit(vpt, dev03, dim, lock):
 def test_device_tesselated_scenes_equal_the_reference(vpt, dev03, scene_file):
     golden = json.load(open(os.path.join(GOLDEN, "substitute_stats.json")))[scene_file]
     assert _stats(vpt, scene_file, tess_device=0) == golden
+
+
+def _random_cage_obj(rng, n, with_uv, holes=True):
+    """an n x n grid cage with holes, some cells as two triangles, some as pentagon + triangle fans; face-varying texcoords"""
+    lines, verts = [], {}
+    for y in range(n + 1):
+        for x in range(n + 1):
+            verts[(x, y)] = len(verts) + 1
+            lines.append(f"v {x * 0.02 + rng.normal() * 0.002:.6f} {0.03 + rng.normal() * 0.01:.6f} {y * 0.02 + rng.normal() * 0.002:.6f}")
+    nvt = 0
+    faces = []
+    vt_of = {}   # a vertex's shared texcoord: corners of one face (distinct vertices) never share an index, which the reference requires
+                 # (a quad whose last two texcoord indices coincide would count as a triangle in one topology and not in the other)
+    for y in range(n):
+        for x in range(n):
+            r = rng.random()
+            if holes and r < 0.15:
+                continue
+            a, b, c, d = verts[(x, y)], verts[(x + 1, y)], verts[(x + 1, y + 1)], verts[(x, y + 1)]
+            cells = [[a, b, c], [a, c, d]] if r < 0.35 else [[a, b, c, d]]
+            for cell in cells:
+                if with_uv:
+                    idx = []
+                    for v in cell:
+                        if v not in vt_of or rng.random() < 0.3:   # a seam: this corner gets a texcoord of its own
+                            nvt += 1
+                            lines.append(f"vt {rng.random():.5f} {rng.random():.5f}")
+                            if v not in vt_of:
+                                vt_of[v] = nvt
+                            idx.append(nvt)
+                        else:
+                            idx.append(vt_of[v])
+                    faces.append("f " + " ".join(f"{v}/{t}" for v, t in zip(cell, idx)))
+                else:
+                    faces.append("f " + " ".join(str(v) for v in cell))
+    return "\n".join(lines + faces) + "\n", len(faces)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_cages_tesselate_like_the_reference_does_now(vpt, tmp_path, seed):
+    """Live comparison where the reference is present (the build container): random cages - open boundaries, holes, triangles,
+    face-varying texture charts, 1 to 3 levels, smooth on / off, displaced or not - through the reference's load_scene +
+    tesselate_surfaces (oracle/_ref/ref_driver --stats) and through ours: the same hashes of all four arrays."""
+    import oracle_lib as O
+    if not O.have_reference():
+        pytest.skip("oracle/_ref is not built here (the committed fixtures pin the same path)")
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(1, 7))
+    with_uv = bool(seed % 2 == 0)
+    text, nfaces = _random_cage_obj(rng, n, with_uv)
+    if nfaces == 0:
+        text, nfaces = _random_cage_obj(rng, n, with_uv, holes=False)
+    (tmp_path / "cage.obj").write_text(text)
+    tex = os.path.join(GOLDEN, "scenes", "shared_textures", "bumps-displacement.png")
+    subdiv = {"name": "s", "shape": 0, "uri": "cage.obj", "subdivisions": int(rng.integers(1, 4)), "smooth": bool(rng.random() < 0.6)}
+    if with_uv and rng.random() < 0.7:
+        subdiv.update(displacement=0.01, displacement_tex=0)
+    scene = {"asset": {"version": "4.2"}, "cameras": [{"name": "c", "aspect": 1.0, "frame": [1, 0, 0, 0, 1, 0, 0, 0, 1, 0.05, 0.05, 0.4]}],
+             "textures": [{"name": "t", "uri": tex}], "materials": [{"name": "m", "type": "matte", "color": [0.5, 0.5, 0.5]}],
+             "shapes": [{"name": "s", "uri": "cage.obj"}], "subdivs": [subdiv], "instances": [{"name": "i", "shape": 0, "material": 0}],
+             "environments": [{"name": "e", "emission": [1, 1, 1]}]}
+    path = tmp_path / "scene.json"
+    path.write_text(json.dumps(scene))
+    *_, ref = O.reference_render(str(path), "eyelight", 16, 1, 4, stats=True, workdir=str(tmp_path))
+    mine = json.loads(vpt.HostScene(str(path)).stats())
+    assert mine["shapes"] == ref["shapes"], (seed, subdiv, mine["shapes"], ref["shapes"])
+    assert mine["scene_bvh"] == ref["scene_bvh"]

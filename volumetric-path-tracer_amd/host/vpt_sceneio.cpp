@@ -49,7 +49,8 @@ static string path_extension(const string& filename) {
   for (auto& c : ext) c = (char)tolower(c);
   return ext;
 }
-static string path_join(const string& a, const string& b) { return a + "/" + b; }
+// std::filesystem's operator/ as the reference uses it (yocto_sceneio.cpp:105-107): an absolute second path replaces the first
+static string path_join(const string& a, const string& b) { return (!b.empty() && b[0] == '/') ? b : a + "/" + b; }
 
 // ---------------------------------------------------------------------------------------------
 // minimal JSON (RFC 8259) — numbers kept as double (strtod), converted on access like the

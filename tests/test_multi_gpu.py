@@ -32,6 +32,24 @@ def test_multi_errors(vpt, scene03):
     multi = vpt.MultiDeviceScene(scene03, [0])
     with pytest.raises(vpt.VptError):
         multi.get_render(64, 27)                             # nothing rendered yet
+    import ctypes as C
+    q = vpt.PathtraceParams(resolution=64, samples=4, shader="volpathtrace")
+    fresh = scene03.make_state(q)
+    with pytest.raises(vpt.VptError, match="no state"):
+        multi.get_state(fresh)                               # nothing on the devices yet
+    n = C.c_int(0)
+    abi = q.to_abi()
+    rc = vpt.hip.vpt_multi_render(multi.handle, C.byref(abi), 1, fresh.width, fresh.height, None, None, None, C.byref(n))
+    assert rc == -1 and b"vpt_multi_set_state first" in vpt.hip.vpt_last_error()       # resident render without a resident state
+    rc = vpt.hip.vpt_multi_render(multi.handle, C.byref(abi), 1, fresh.width, fresh.height, fresh.image.ctypes.data, None, None, C.byref(n))
+    assert rc == -1                                          # host pointers: all three or none
+    assert vpt.hip.vpt_multi_set_state(multi.handle, 0, 27, fresh.image.ctypes.data, fresh.hits.ctypes.data, fresh.rngs.ctypes.data, 0) == -1
+    assert vpt.hip.vpt_multi_set_state(multi.handle, 64, 27, None, fresh.hits.ctypes.data, fresh.rngs.ctypes.data, 0) == -1
+    multi.set_state(fresh)
+    multi._resident = (fresh.width, fresh.height, 3)        # the caller claims a sample count the devices do not hold
+    with pytest.raises(vpt.VptError):
+        multi.render_resident(q, 1)
+    assert multi.transport() == "local" and vpt.hip.vpt_multi_transport(None) == b""
     with pytest.raises(vpt.VptError):
         p = vpt.PathtraceParams(resolution=64, samples=2, shader="volpathtrace")
         st = scene03.make_state(p)

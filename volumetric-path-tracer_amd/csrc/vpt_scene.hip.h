@@ -902,9 +902,6 @@ VPT_DEV float sd_capped_cone(f3 p, float h, float r1, float r2) {
 // Where the records are read from: the scene's tables in HBM (DScene::sdf_fn_rec / sdf_grid_rec), or a copy a kernel made
 // in its LDS (K2: the records are wave-uniform and read six times per march step; from HBM each read is a vector load
 // with its full latency on the critical path of the step, from LDS a broadcast ds_read).
-#ifndef VPT_SDF_PREFETCH
-#define VPT_SDF_PREFETCH 0   // eval_sdf_scene fetches the next voxel-grid record while it evaluates the current one
-#endif
 struct sdf_recs { const float4 *fn, *grid; };
 VPT_DEV sdf_recs scene_sdf_recs(const DScene& sc) { sdf_recs r = {sc.sdf_fn_rec, sc.sdf_grid_rec}; return r; }
 VPT_DEV f3 sdf_to_local(const float4* rec, bool translation, f3 pw) {
@@ -951,8 +948,8 @@ VPT_DEV float eval_volume(const DScene& sc, const vpt_volume& vol, f3 uvw) {
          v111 * u * v * w;
 }
 // eval_sdf(volume, instance, p_local, t) behind the instance's transform, yocto_sdfs.cpp:13 + 30-49.  r2 / hf: the record's
-// words [2] and [4] (translation, half box size | translation flag), handed in so that a caller walking over the records can
-// fetch the next instance's while this one is evaluated (they come from LDS: ~100 cycles that nothing else would cover)
+// words [2] and [4] (translation, half box size | translation flag).  (Fetching the next instance's words during this
+// evaluation was measured twice - 315 = 315 Msamples/s at four waves per SIMD, 331 against 348 at five: the extra registers spill.)
 VPT_DEV float sdf_grid_world(const DScene& sc, const float4* rec, float4 r2, float4 hf, f3 pw, float t) {
   f3 p = (__float_as_int(hf.w) & 1) ? mk3(pw.x + r2.y, pw.y + r2.z, pw.z + r2.w) : transform_point(unpack_frame(rec[0], rec[1], r2), pw);
   float  bbox_dist = sd_box(p - xyz(hf), xyz(hf));
@@ -973,23 +970,10 @@ VPT_DEV float sdf_grid_world(const DScene& sc, const sdf_recs& recs, int idx, f3
 struct sdf_hit { float result; int instance, sdf; };
 VPT_DEV sdf_hit eval_sdf_scene(const DScene& sc, const sdf_recs& recs, f3 p, float t) {   // yocto_sdfs.cpp:7-26 (first minimum wins ties)
   sdf_hit res = {VPT_FLT_MAX, -1, -1};
-#if VPT_SDF_PREFETCH
-  const int nvol = sc.num_vol_instances;
-  float4 r2 = make_float4(0, 0, 0, 0), hf = r2;
-  if (nvol > 0) r2 = recs.grid[2], hf = recs.grid[4];
-  for (int idx = 0; idx < nvol; idx++) {
-    const float4* rec = recs.grid + 7 * idx;
-    const float4 r2c = r2, hfc = hf;
-    if (idx + 1 < nvol) r2 = rec[7 + 2], hf = rec[7 + 4];   // the next instance's words, in flight during this evaluation
-    float d = sdf_grid_world(sc, rec, r2c, hfc, p, t);
-    if (d < res.result) res.result = d, res.instance = idx, res.sdf = -1;
-  }
-#else
   for (int idx = 0; idx < sc.num_vol_instances; idx++) {
     float d = sdf_grid_world(sc, recs, idx, p, t);
     if (d < res.result) res.result = d, res.instance = idx, res.sdf = -1;
   }
-#endif
   for (int idx = 0; idx < sc.num_sdfs; idx++) {
     float d = sdf_fn_world(recs, idx, p);
     if (d < res.result) res.result = d, res.instance = -1, res.sdf = idx;

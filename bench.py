@@ -30,6 +30,8 @@ The JSON line carries, besides the driver's contract:
   cpu_baseline   the reference's own renderer (oracle/_ref/ref_driver, "reference": all hardware threads as the
                  reference starts them, plus `single_thread`) and our CPU restatement at one thread per core (`port`),
                  timed on this host's cores on bounded samples of the same workload.  Rank 0, N=1 only.
+  rccl_path_one_rank  (N = 1) the collective path of --gpus N run with one rank in a child process (`--dist`): proof in the line itself
+                 that the RCCL calls of the one-process-per-GPU front end execute on the box the line was measured on.
   other_configs  (N = 1) the other BASELINE configs' workloads, a few steps each after the timed region: config 3's
                  substitute scene (05_head1ss_sub volpathtrace), config 4's (06_gridsdf_synth implicit), config 5's frame
                  (03_volume 3840x1600), each with its own cold first call and roofline record.
@@ -130,8 +132,9 @@ class Bench:
             if self.rehearsal:
                 dist.init_process_group("gloo")
             elif self.world == 1:   # --dist: the N > 1 code path at world size 1 (RCCL communicator of one rank)
-                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29500 + os.getpid() % 2000}", rank=0, world_size=1,
-                                        device_id=self.device)
+                import tempfile
+                rendezvous = os.path.join(tempfile.gettempdir(), f"vpt_bench_rendezvous_{os.getpid()}")   # a file: no port to collide on
+                dist.init_process_group("nccl", init_method=f"file://{rendezvous}", rank=0, world_size=1, device_id=self.device)
             else:
                 dist.init_process_group("nccl", device_id=self.device)
         self.stream = torch.cuda.current_stream().cuda_stream
@@ -384,6 +387,20 @@ def main():
                                "steps": 3, "warmup": 1, "ms_per_step": round(ms, 3), "value": round(wo.samples_per_step / ms * 1e-3, 3),
                                "unit": "Msamples/s", "cold": first, "roofline": B.roofline(wo)})
                 del wo
+        rccl_path = None
+        if world == 1 and default_workload and not args.no_others and not args.dist:
+            # the N > 1 code path with one rank, in a process of its own (a failure there must not cost the headline line):
+            # nccl (= RCCL) process group, all_gather_into_tensor of the tile buffer and the resolve of the gathered buffer per step
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--dist", "--steps", "3", "--warmup", "1", "--no-cold", "--no-others", "--cpu-sample", "0"]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                sub = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                rccl_path = {"ok": True, "value": sub["value"], "unit": "Msamples/s", "ms_per_step": sub["ms_per_step"], "steps": 3,
+                             "what": "bench.py --dist: the same workload with every step ending in all_gather_into_tensor over an nccl (RCCL) "
+                                     "process group of ONE rank + resolve of the gathered buffer - the collective path of --gpus N, executed on this box"}
+            except Exception as e:   # noqa: BLE001
+                rccl_path = {"ok": False, "error": repr(e)[:300]}
         if world == 1:
             workload_note = ""
         elif args.weak:
@@ -414,6 +431,8 @@ def main():
             line["config5"] = config5
         if others:
             line["other_configs"] = others
+        if rccl_path:
+            line["rccl_path_one_rank"] = rccl_path
         print(json.dumps(line), flush=True)
     if B.dist is not None:
         B.dist.barrier()

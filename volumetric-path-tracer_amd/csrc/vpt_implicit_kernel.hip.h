@@ -89,7 +89,7 @@ VPT_DEV int scene_march_step(const DScene& sc, const sdf_recs& recs, f3 ro, f3 r
   if (!(it < maxiter && t < VPT_FLT_MAX)) return M_MISS;
   f3      p   = ro + rd * t;
   sdf_hit res = eval_sdf_scene(sc, recs, p, t);
-  if (fabs_(res.result) < (VPT_FLT_EPS * t)) {
+  if (__builtin_fabsf(res.result) < (VPT_FLT_EPS * t)) {   // |x| < y and the ternary abs(x) < y agree for every x (they differ in the sign of a zero only)
     hit_instance = res.instance, hit_sdf = res.sdf;
     return M_HIT;
   }
@@ -120,7 +120,7 @@ VPT_DEV bool light_march_step(const sdf_recs& recs, int sdf, float area, f3 posi
   if (!(lit < maxiter && lt < VPT_FLT_MAX)) return false;
   f3    p   = position + direction * lt;
   float res = sdf_fn_world(recs, sdf, p);
-  if (fabs_(res) < (VPT_FLT_EPS * lt)) {
+  if (__builtin_fabsf(res) < (VPT_FLT_EPS * lt)) {
     f3 lnormal = eval_sdf_normal_function(recs, sdf, position, lt);
     sum += distance_squared(p, position) / (fabs_(dot(lnormal, direction)) * area);
     return false;

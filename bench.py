@@ -134,6 +134,8 @@ class Bench:
             elif self.world == 1:   # --dist: the N > 1 code path at world size 1 (RCCL communicator of one rank)
                 import tempfile
                 rendezvous = os.path.join(tempfile.gettempdir(), f"vpt_bench_rendezvous_{os.getpid()}")   # a file: no port to collide on
+                if os.path.exists(rendezvous):   # a leftover of an earlier process with this pid would be read as that job's store
+                    os.remove(rendezvous)
                 dist.init_process_group("nccl", init_method=f"file://{rendezvous}", rank=0, world_size=1, device_id=self.device)
             else:
                 dist.init_process_group("nccl", device_id=self.device)

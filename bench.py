@@ -408,8 +408,8 @@ def main():
         elif args.weak:
             workload_note = ", frame grows with N"
         else:
-            workload_note = (", fixed frame (a pixel's samples are a serial RNG chain: the costliest 8x8 tile bounds the launch, so this frame "
-                             "cannot scale past ~2.4x at 8 GPUs; see config5 for the 3840x1600 frame)")
+            workload_note = (", fixed frame (a pixel's samples are a serial RNG chain: the costliest 8x8 tile bounds the launch; `serial_chain` "
+                             "holds the bound measured in this run" + ("; `config5` is the 3840x1600 frame" if config5 else "") + ")")
         line = {
             "metric": "Msamples/sec", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -427,6 +427,15 @@ def main():
         if cold:
             line["cold"] = cold
         if single:
+            # what the serial chain allows on this frame, from this run's own launch: rank 0's costliest wave (100 MHz ticks the kernel
+            # records per wave) against the time the whole frame took on rank 0 alone
+            c = w.dev.last_wave_costs().astype(np.float64) * 1e-5
+            c = c[c > 0]
+            if len(c):
+                line["serial_chain"] = {"longest_wave_ms_rank0": round(float(c.max()), 3), "mean_wave_ms_rank0": round(float(c.mean()), 4),
+                                        "waves_rank0": int(len(c)), "single_gpu_ms": single["ms_per_step"],
+                                        "speedup_bound": round(single["ms_per_step"] / float(c.max()), 3),
+                                        "what": "a launch is never shorter than its costliest wave: speed-up over one GPU <= single_gpu_ms / longest_wave_ms (measured here, not a constant)"}
             line["single_gpu"] = single
             line["speedup_vs_1gpu"] = round(single["ms_per_step"] / (elapsed / args.steps * 1e3), 3)
         if config5:

@@ -264,13 +264,14 @@ int vpt_render(vpt_scene* scene, const vpt_params* params, int nsamples, int wid
  * (the reference's pathtrace_state is the same progressive accumulator, yocto_pathtrace.h:57-64).
  *   vpt_multi_set_state   host pathtrace_state -> devices (pinned staging, one thread per GPU)
  *   vpt_multi_render      with null image/hits/rng: `nsamples` passes on the resident state, nothing is transferred;
- *                         with host pointers: the contract of vpt_render - the arrays are current after the call
- *                         (yocto_pathtrace.cpp:1081-1090) - and the upload is skipped when they still are the state
- *                         this handle stored there after its last render (same size, same *samples_io > 0, and 64
- *                         probe pixels spread over the frame - RNG words, sum, hit count - unchanged).  A caller that
- *                         edits the arrays in place between two calls announces it with vpt_multi_set_state (any change
- *                         of size or sample count, e.g. a fresh make_state, is seen without it); VPT_MULTI_RESIDENT=0
- *                         makes every call upload.
+ *                         with host pointers: the contract of vpt_render - the arrays ARE the state: they are read on
+ *                         every call and current after it (yocto_pathtrace.cpp:1081-1090).  RULE: a device's part of
+ *                         the upload is skipped only if the device provably holds it - the three arrays are the very
+ *                         ones (same addresses, size, *samples_io > 0) the previous call on this handle downloaded
+ *                         into, and a 64-bit checksum over every word of that part (taken after the download, re-taken
+ *                         from the arrays now) is unchanged.  An in-place edit of any pixel, another state object, a
+ *                         fresh make_state: uploaded, nothing to announce.  VPT_MULTI_RESIDENT=0 makes every call
+ *                         upload everything; vpt_multi_uploaded_parts() tells what the last call did.
  *   vpt_multi_get_state   devices -> host arrays, on demand
  *   vpt_multi_get_render  get_render of the resident state, assembled on devices[0]: the float4 tile buffers travel there
  *                         over xGMI by grouped RCCL send / receive (RCCL is bound on first use, a copy the process already
@@ -293,6 +294,8 @@ int  vpt_multi_render(vpt_multi* m, const vpt_params* params, int nsamples, int 
 /* get_render (yocto_pathtrace.cpp:1105-1116) of the resident state: row-major float4 image * (1 / samples) into the
  * caller's host buffer, gathered and resolved on devices[0] */
 int  vpt_multi_get_render(vpt_multi* m, float* image_rgba);
+/* how many devices' parts the last vpt_multi_render call with host pointers uploaded (0 ... device count) */
+int  vpt_multi_uploaded_parts(const vpt_multi* m);
 
 /* ---- device-resident state (bench / multi-GPU; buffers owned by the caller, e.g. torch) */
 /* number of state slots a rank needs for `layout` (multiple of tile_w*tile_h) */

@@ -174,6 +174,17 @@ FULL_SIZE = {  # BASELINE.json configs at their full frame sizes: (scene, shader
 FULL_SIZE_PIXELS = 4096
 
 
+def _sampled_pixels(size):
+    """a seeded sample of FULL_SIZE_PIXELS pixels of a frame, a quarter of it from the frame's last rows and columns (where ragged
+    tiles and the end of the launch order live), as sorted row-major indices"""
+    rng = np.random.default_rng(size[0] * 7 + size[1])
+    w, hgt = size
+    pix = rng.choice(w * hgt, FULL_SIZE_PIXELS * 3 // 4, replace=False)
+    edge_y = rng.integers(hgt - 16, hgt, FULL_SIZE_PIXELS // 8) * w + rng.integers(0, w, FULL_SIZE_PIXELS // 8)
+    edge_x = rng.integers(0, hgt, FULL_SIZE_PIXELS // 8) * w + rng.integers(w - 16, w, FULL_SIZE_PIXELS // 8)
+    return np.unique(np.concatenate([pix, edge_y, edge_x])).astype(np.int32)
+
+
 @pytest.mark.parametrize("name", sorted(FULL_SIZE))
 def test_full_size_properties(vpt, oracle, name):
     """The BASELINE frame sizes: size-independent properties of the whole frame + the STRICT per-pixel check of the module
@@ -196,14 +207,9 @@ def test_full_size_properties(vpt, oracle, name):
     dev.pathtrace_samples(h, p, 1)
     dev.pathtrace_samples(h, p, spp - 1)
     assert np.array_equal(h.image.view(np.uint32), g.image.view(np.uint32)) and np.array_equal(h.rngs, g.rngs)
-    # pixel-exact parity on a seeded sample of the full-size frame (a quarter of it from the frame's last rows and columns,
-    # where ragged tiles and the end of the launch order live)
-    rng = np.random.default_rng(size[0] * 7 + size[1])
+    # pixel-exact parity on a seeded sample of the full-size frame
     w, hgt = size
-    pix = rng.choice(w * hgt, FULL_SIZE_PIXELS * 3 // 4, replace=False)
-    edge_y = rng.integers(hgt - 16, hgt, FULL_SIZE_PIXELS // 8) * w + rng.integers(0, w, FULL_SIZE_PIXELS // 8)
-    edge_x = rng.integers(0, hgt, FULL_SIZE_PIXELS // 8) * w + rng.integers(w - 16, w, FULL_SIZE_PIXELS // 8)
-    pix = np.unique(np.concatenate([pix, edge_y, edge_x])).astype(np.int32)
+    pix = _sampled_pixels(size)
     q = vpt.PathtraceParams(resolution=res, samples=spp, shader=shader, bounces=bounces)
     ref = scene.make_state(q)
     oracle.oracle_render(scene, q, ref, spp, nthreads=0, pixels=pix)
@@ -211,6 +217,34 @@ def test_full_size_properties(vpt, oracle, name):
     untouched[pix] = False
     assert (ref.image.reshape(-1, 4)[untouched] == 0).all()   # the oracle rendered the sampled pixels only
     _check_against_reference(oracle, scene, q, spp, g, ref.image, ref.rngs, name + f" {w}x{hgt}x{spp}", *floors, pixels=pix)
+
+
+LONG_CHAIN = {  # configs 3 and 4 at their full frame, 256 samples of a pixel's serial PCG32 chain (their BASELINE spp are 1024 / 512; the
+    # cases above hold them to the reference for 4).  Floors on (identical streams, matching, stable) just under the MI355X-measured shares.
+    # A pixel's stream survives 256 samples only if none of its ~700 (head) / ~1 500 (sdf) libm-dependent decisions flips, so the
+    # identical-stream share is lower than at 4 spp by construction; what the strict check demands is unchanged: a pixel may differ
+    # only where the reference's own value moves under 1-ulp libm nudges.
+    "config3_05_head_1280x256": ("05_head1ss_sub/head1ss_sub.json", "volpathtrace", 1280, 64, (1280, 1280), 256, (0.90, 0.90, 0.50)),
+    "config4_06_gridsdf_1280x256": ("06_gridsdf_full/gridsdf_full.json", "implicit", 1280, 4, (1280, 533), 256, (0.60, 0.55, 0.30)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(LONG_CHAIN))
+def test_long_chains_on_the_big_scenes(vpt, oracle, name):
+    """256 samples per pixel on the 144 046-triangle scene (K1, overflow-stack instance) and on the 96^3 + 64^3 voxel scene (K2):
+    the full frame on the device in one call, the oracle on a seeded sample of 4 096 of its pixels, the strict per-pixel check."""
+    scene_file, shader, res, bounces, size, spp, floors = LONG_CHAIN[name]
+    scene = vpt.HostScene(os.path.join(GOLDEN, "scenes", scene_file))
+    dev = vpt.DeviceScene(scene, 0)
+    q = vpt.PathtraceParams(resolution=res, samples=spp, shader=shader, bounces=bounces)
+    g = scene.make_state(q)
+    dev.pathtrace_samples(g, q, spp)
+    assert (g.width, g.height, g.samples) == (*size, spp)
+    assert (g.hits == spp).all() and np.isfinite(g.image).all()
+    pix = _sampled_pixels(size)
+    ref = scene.make_state(q)
+    oracle.oracle_render(scene, q, ref, spp, nthreads=0, pixels=pix)
+    _check_against_reference(oracle, scene, q, spp, g, ref.image, ref.rngs, name + f" {size[0]}x{size[1]}x{spp}", *floors, pixels=pix)
 
 
 def _rms_vs_check(vpt, state, check_name):

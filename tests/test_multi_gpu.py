@@ -81,18 +81,21 @@ def test_state_stays_resident_between_calls(vpt, scene03, dev03):
     assert st.samples == 12 and (st.hits == 12).all()
     assert np.array_equal(st.image.view(np.uint32), ref.image.view(np.uint32)) and np.array_equal(st.rngs, ref.rngs)
 
-    # host-pointer calls: upload skipped on the second call (probes match) - and the result is the same either way
+    # host-pointer calls: upload skipped on the second call (same arrays, same checksum) - and the result is the same either way
     half = scene03.make_state(p)
     dev03.pathtrace_samples(half, p, 3)
     a = scene03.make_state(p)
     multi.pathtrace_samples(a, p, 1)
+    assert multi.uploaded_parts() == 3
     multi.pathtrace_samples(a, p, 2)
+    assert multi.uploaded_parts() == 0
     assert np.array_equal(a.image.view(np.uint32), half.image.view(np.uint32)) and np.array_equal(a.rngs, half.rngs)
     # the caller swaps in another state with the same sample count: a fresh state advanced by another handle
     b = scene03.make_state(p)
     dev03.pathtrace_samples(b, p, 3)
-    b.image[:] = 0                                               # ... and edited (the probes see it)
+    b.image[:] = 0                                               # ... and edited
     multi.pathtrace_samples(b, p, 1)
+    assert multi.uploaded_parts() == 3
     expect = scene03.make_state(p)
     dev03.pathtrace_samples(expect, p, 3)
     expect.image[:] = 0
@@ -106,6 +109,53 @@ def test_state_stays_resident_between_calls(vpt, scene03, dev03):
     with pytest.raises(vpt.VptError):
         multi._resident = (st.width, st.height, 5)
         multi.render_resident(p, 1)
+
+
+def test_the_callers_arrays_are_the_state(vpt, scene03, dev03):
+    """The reference reads the live pathtrace_state on every call (yocto_pathtrace.cpp:1081-1090).  The host-pointer form of
+    vpt_multi_render may skip a device's upload only when that device provably holds the caller's data (include/vpt.h, the
+    RULE): (1) an in-place edit of ONE pixel - of the radiance sum only, RNG state and hit count untouched, the kind of
+    edit round 3's 64-pixel probe could not see - reaches the result, and only the device that owns the pixel uploads;
+    (2) two state objects rendered alternately at equal sample counts through one handle (two shaders on one scene is how
+    the drop-in meets this) never continue from each other's device buffers, although they agree on every background pixel."""
+    p = vpt.PathtraceParams(resolution=200, samples=8, shader="volpathtrace", bounces=64)
+    multi = vpt.MultiDeviceScene(scene03, [0, 0, 0])
+    a = scene03.make_state(p)
+    multi.pathtrace_samples(a, p, 2)
+    ref = a.copy()
+    # (1) one pixel, one word; its tile decides which device must upload (tile t -> devices[t % 3])
+    y, x = 41, 77
+    a.image[y, x, 1] += 0.25
+    ref.image[y, x, 1] += 0.25
+    multi.pathtrace_samples(a, p, 2)
+    assert multi.uploaded_parts() == 1
+    dev03.pathtrace_samples(ref, p, 2)
+    assert np.array_equal(a.image.view(np.uint32), ref.image.view(np.uint32)) and np.array_equal(a.rngs, ref.rngs)
+    multi.pathtrace_samples(a, p, 1)                             # untouched since: nothing to upload
+    assert multi.uploaded_parts() == 0
+    a.rngs[3, 5, 0] ^= 1                                         # an RNG word of another pixel
+    multi.pathtrace_samples(a, p, 1)
+    assert multi.uploaded_parts() == 1
+    # (2) alternating states, same size and sample count at every call
+    q = vpt.PathtraceParams(resolution=200, samples=8, shader="pathtrace", bounces=8)
+    s1, s2 = scene03.make_state(p), scene03.make_state(q)
+    r1, r2 = s1.copy(), s2.copy()
+    for _ in range(3):
+        multi.pathtrace_samples(s1, p, 2)
+        assert multi.uploaded_parts() == 3
+        multi.pathtrace_samples(s2, q, 2)
+        assert multi.uploaded_parts() == 3
+        dev03.pathtrace_samples(r1, p, 2)
+        dev03.pathtrace_samples(r2, q, 2)
+    assert s1.samples == s2.samples == 6
+    assert np.array_equal(s1.image.view(np.uint32), r1.image.view(np.uint32)) and np.array_equal(s1.rngs, r1.rngs)
+    assert np.array_equal(s2.image.view(np.uint32), r2.image.view(np.uint32)) and np.array_equal(s2.rngs, r2.rngs)
+    # a copy at another address with identical contents is uploaded too (the addresses are part of the key) - same bits either way
+    s3 = s2.copy()
+    multi.pathtrace_samples(s3, q, 1)
+    assert multi.uploaded_parts() == 3
+    dev03.pathtrace_samples(r2, q, 1)
+    assert np.array_equal(s3.image.view(np.uint32), r2.image.view(np.uint32))
 
 
 def test_rccl_entry_points_run_on_one_gpu(vpt, scene03, dev03, monkeypatch):

@@ -76,6 +76,18 @@ def test_obj_reader_follows_the_references_rules(vpt, tmp_path):
     # point / line elements are outside the hot-path scope: loaded, then rejected when the scene is flattened
     with pytest.raises(vpt.VptError):
         _load_shape_via_scene(vpt, tmp_path, "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\nl 1 2\n")
+    # ... and in a subdivision cage they are refused at load time: the reference's get_fvquads (yocto_modelio.cpp:2446) skips such an
+    # element without advancing its vertex cursor, so it would read every later face from the wrong vertices (deliberate divergence)
+    with pytest.raises(vpt.VptError, match="line / point elements"):
+        _load_shape_via_scene(vpt, tmp_path, "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nl 1 2\nf 1 2 3 4\n", subdiv={"subdivisions": 1})
+    # a literal longer than any fixed window is ONE number (round 3 copied 63 characters and read the tail as the next coordinate)
+    long_one = "1." + "0" * 80 + "5"
+    st = _load_shape_via_scene(vpt, tmp_path, f"v 0 0 0\nv {long_one} 0 0\nv 0 1 0\nf 1 2 3\n")["shapes"][0]
+    assert (st["positions"], st["triangles"]) == (3, 1)
+    with pytest.raises(vpt.VptError, match="parse error"):   # the same literal where only two coordinates follow "v": not three numbers
+        _load_shape_via_scene(vpt, tmp_path, f"v 0 0 0\nv {long_one} 0\nv 0 1 0\nf 1 2 3\n")
+    with pytest.raises(vpt.VptError, match="parse error"):   # an index that overflows the reader's window
+        _load_shape_via_scene(vpt, tmp_path, "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 " + "3" * 40 + "\n")
 
 
 def test_a_subdiv_replaces_its_shape_entirely(vpt, tmp_path):

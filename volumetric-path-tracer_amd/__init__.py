@@ -110,6 +110,7 @@ hip.vpt_multi_destroy.restype = None
 hip.vpt_multi_device_count.argtypes = [_p]
 hip.vpt_multi_render.argtypes = [_p, C.POINTER(VptParams), C.c_int, C.c_int, C.c_int, _p, _p, _p, C.POINTER(C.c_int)]
 hip.vpt_multi_get_render.argtypes = [_p, _p]
+hip.vpt_multi_uploaded_parts.argtypes = [_p]
 hip.vpt_multi_transport.argtypes = [_p]
 hip.vpt_multi_transport.restype = C.c_char_p
 hip.vpt_multi_set_state.argtypes = [_p, C.c_int, C.c_int, _p, _p, _p, C.c_int]
@@ -326,8 +327,8 @@ class MultiDeviceScene:
         self.handle = out
 
     def pathtrace_samples(self, state: PathtraceState, params: PathtraceParams, count: int = 1) -> None:
-        """host state in, host state out (the contract of vpt_render); the upload is skipped while `state` still is what the
-        last call stored (include/vpt.h)"""
+        """host state in, host state out (the contract of vpt_render); a device's part of the upload is skipped only while `state`'s
+        arrays are the very ones the last call downloaded into and their checksum over every word is unchanged (include/vpt.h)"""
         abi = params.to_abi()
         samples = C.c_int(state.samples)
         _check(hip.vpt_multi_render(self.handle, C.byref(abi), count, state.width, state.height, state.image.ctypes.data,
@@ -357,6 +358,10 @@ class MultiDeviceScene:
 
     def transport(self) -> str:
         return hip.vpt_multi_transport(self.handle).decode()
+
+    def uploaded_parts(self) -> int:
+        """devices whose part of the caller's arrays the last pathtrace_samples call uploaded (include/vpt.h: the residency rule)"""
+        return hip.vpt_multi_uploaded_parts(self.handle)
 
     def get_render(self, width: int, height: int) -> np.ndarray:
         out = np.zeros((height, width, 4), np.float32)

@@ -258,6 +258,8 @@ struct vpt_scene {
   void *r_image = nullptr, *r_hits = nullptr, *r_rng = nullptr;   // row-major mirror
   long long  staged_pixels = 0, staged_slots = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_host0 = nullptr, ev_host1 = nullptr;   // around a host-side pause inside a call (decide_split): not kernel time
+  bool       host_pause = false;                       // the last call recorded that pair
   bool       timed = false;
   unsigned*  d_watchdog = nullptr;   // waves of the implicit kernel that gave up (must stay 0; vpt_implicit_kernel.hip.h)
   bool       large_mesh_lights = false;
@@ -444,8 +446,8 @@ void vpt_scene_destroy(vpt_scene* s) {
     if (p) (void)hipFree(p);
   if (s->ev_order) (void)hipEventDestroy(s->ev_order);
   if (s->d_watchdog) (void)hipFree(s->d_watchdog);
-  if (s->ev0) (void)hipEventDestroy(s->ev0);
-  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  for (hipEvent_t e : {s->ev0, s->ev1, s->ev_host0, s->ev_host1})
+    if (e) (void)hipEventDestroy(e);
   delete s;
 }
 
@@ -843,6 +845,8 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   }
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
+  HIP_TRY(hipEventCreate(&s->ev_host0));
+  HIP_TRY(hipEventCreate(&s->ev_host1));
   HIP_TRY(hipMalloc((void**)&s->d_watchdog, 4));
   HIP_TRY(hipMemset(s->d_watchdog, 0, 4));
   HIP_TRY(hipEventCreateWithFlags(&s->ev_order, hipEventDisableTiming));
@@ -1159,8 +1163,12 @@ static int launch_mesh(const launch_ctx& L) {
     bool is_pilot = parts[1] > 0 && part == 0;
     // the costs of an unsplit launch over at least 8 samples decide, once, whether tiles are split from now on
     if (may_split && !s->split_decided && s->order_valid && s->full_costs) {
+      // the decision waits for the stream and reads costs back on the host: that pause is bracketed by its own event pair and
+      // subtracted by vpt_last_kernel_ms (a pilot launch that ran before it in this call stays counted)
+      HIP_TRY(hipEventRecord(s->ev_host0, L.st));
       if (int rc = decide_split(s, pr, (int)L.grid.x, s->wave_slots_k1, L.st)) return rc;
-      HIP_TRY(hipEventRecord(s->ev0, L.st));   // the decision waited for the stream and read costs back on the host: not kernel time (vpt_last_kernel_ms)
+      HIP_TRY(hipEventRecord(s->ev_host1, L.st));
+      s->host_pause = true;
     }
     dim3 grid = s->split_waves > 0 ? dim3((unsigned)s->split_waves) : L.grid;
     sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, s->split_waves > 0 ? s->d_lane_slot : nullptr};
@@ -1255,6 +1263,7 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
   auto   hit = (int*)d_hits;
   auto   rng = (ulonglong2*)d_rng;
   HIP_TRY(hipEventRecord(s->ev0, st));
+  s->host_pause = false;
   launch_ctx L = {s, params, pr, grid, block, st, img, hit, rng, stack};
   int rc = VPT_OK;
   switch (params->shader) {
@@ -1302,6 +1311,11 @@ int vpt_last_kernel_ms(vpt_scene* s, float* ms) {
   if (!s->timed) return fail(VPT_ERR_INVALID_ARG, "no launch recorded");
   HIP_TRY(hipEventSynchronize(s->ev1));
   HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
+  if (s->host_pause) {
+    float pause = 0;
+    HIP_TRY(hipEventElapsedTime(&pause, s->ev_host0, s->ev_host1));
+    *ms -= pause;
+  }
   return vpt_check_watchdog(s);
 }
 

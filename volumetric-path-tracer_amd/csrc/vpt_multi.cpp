@@ -6,11 +6,15 @@
 // Residency ("each GPU keeps its tiles' image/hits/rng resident across sample batches").  The tile state
 // lives on the devices between calls.  vpt_multi_set_state uploads a host pathtrace_state, vpt_multi_get_state downloads
 // it, vpt_multi_render with null host pointers renders on what is resident and moves nothing.  vpt_multi_render with
-// host pointers keeps the contract of vpt_render (the caller's arrays are valid after every call, yocto_pathtrace.cpp:
-// 1081-1090) and still skips the upload when the arrays are the state it wrote there last time: same size, same sample
-// count, and a probe of 64 pixels spread over the frame (RNG words, radiance sum, hit count: the RNG words change with
-// every sample of every pixel) still reads what the last download stored.  Host staging is pinned (hipHostMalloc), one
-// tile-major buffer per device; the row-major <-> tile-major scatter runs in the per-device threads.
+// host pointers keeps the contract of vpt_render (the caller's arrays are valid after every call and are READ on every
+// call, as the reference reads the live state, yocto_pathtrace.cpp:1081-1090).  A device's part of the upload is skipped
+// only when it is certain that the device already holds it: same frame size and sample count, the SAME three base
+// pointers as the call that last downloaded into them, and a 64-bit checksum over EVERY word of the part (radiance sum,
+// hit count, RNG state of each of its pixels), taken by the device's thread when it stored the download and taken again
+// from the caller's arrays before the skip - one edited pixel anywhere, or another state object at another address,
+// is uploaded (round 3 compared 64 probe pixels only; tests/test_multi_gpu.py edits a pixel no probe looked at).
+// VPT_MULTI_RESIDENT=0 switches the skip off altogether.  Host staging is pinned (hipHostMalloc), one tile-major buffer
+// per device; the row-major <-> tile-major scatter runs in the per-device threads.
 //
 // The one exchange is the frame assembly of vpt_multi_get_render: the float4 tile buffers travel to devices[0] over
 // xGMI with RCCL (grouped ncclSend / ncclRecv: ndev - 1 concurrent point-to-point transfers, no ring, no reduction) and
@@ -110,15 +114,11 @@ struct device_part {
   float*    h_image = nullptr;   // pinned staging, tile-major
   int32_t*  h_hits  = nullptr;
   uint64_t* h_rng   = nullptr;
+  uint64_t  mirror_sum = 0;      // checksum of this part of the caller's arrays as the last download left it
+  bool      mirrored   = false;  // mirror_sum describes what the device holds now
+  bool      uploaded   = false;  // the last render call uploaded this part (vpt_multi_uploaded_parts, tests)
   int         rc = VPT_OK;
   std::string error;
-};
-
-struct probe {   // what the last download stored at one pixel of the caller's arrays
-  size_t   pixel;
-  float    image[4];
-  int32_t  hits;
-  uint64_t rng[2];
 };
 
 }  // namespace
@@ -127,7 +127,7 @@ struct vpt_multi {
   std::vector<device_part> parts;
   int  width = 0, height = 0, samples = 0;   // the frame the device buffers are sized for / the samples they hold
   bool resident = false;                     // the device buffers hold a state (set_state or a render put it there)
-  std::vector<probe> probes;                 // of the host arrays that mirrored the resident state after the last download
+  const void *mirror_image = nullptr, *mirror_hits = nullptr, *mirror_rng = nullptr;   // the caller's arrays the last download wrote (part of the residency key)
   bool distinct = true;                      // all devices different
   bool use_rccl = false;                     // frame assembly by ncclSend / ncclRecv (else hipMemcpyPeerAsync)
   rccl_api                rccl;
@@ -136,6 +136,10 @@ struct vpt_multi {
 };
 
 namespace {
+void forget_mirror(vpt_multi* m) {
+  m->mirror_image = m->mirror_hits = m->mirror_rng = nullptr;
+  for (auto& p : m->parts) p.mirrored = false;
+}
 void free_buffers(vpt_multi* m) {
   for (auto& p : m->parts) {
     if (!p.scene) continue;   // never came to life on its device (vpt_multi_create failed before it)
@@ -150,7 +154,7 @@ void free_buffers(vpt_multi* m) {
     if (*b) (void)hipFree(*b), *b = nullptr;
   m->width = m->height = m->samples = 0;
   m->resident = false;
-  m->probes.clear();
+  forget_mirror(m);
 }
 #define HIP_OK(expr, p)                                                                       \
   do {                                                                                        \
@@ -196,6 +200,26 @@ int fan_out(vpt_multi* m, F work) {
   return VPT_OK;
 }
 
+// 64-bit checksum over every word of one device's part of the caller's arrays.  Per pixel the five words (two of the
+// radiance sum, the hit count, two of the RNG state) enter a multilinear form with odd multipliers, offset by the pixel's
+// index: a change of any single word changes the pixel's term for certain (multiplication by an odd number is a bijection
+// mod 2^64, and so is x ^ x >> 29), several changes at once cancel with probability 2^-64.
+uint64_t part_checksum(const device_part& p, const float* image_rgba, const int32_t* hits, const uint64_t* rng) {
+  uint64_t sum = 0;
+  const size_t n = p.pixel_of_slot.size();
+  for (size_t s = 0; s < n; s++) {
+    int px = p.pixel_of_slot[s];
+    if (px < 0) continue;
+    uint64_t w[2];
+    memcpy(w, image_rgba + 4 * (size_t)px, 16);
+    uint64_t h = ((uint64_t)px + 1) * 0x9e3779b97f4a7c15ull;
+    h += w[0] * 0xff51afd7ed558ccdull + w[1] * 0xc4ceb9fe1a85ec53ull + (uint64_t)(uint32_t)hits[px] * 0xd6e8feb86659fd93ull;
+    h += rng[2 * (size_t)px] * 0x2545f4914f6cdd1dull + rng[2 * (size_t)px + 1] * 0x94d049bb133111ebull;
+    sum += h ^ (h >> 29);
+  }
+  return sum;
+}
+
 // part i: the caller's row-major arrays -> pinned tile-major staging -> device
 void upload_part(vpt_multi* m, int i, const float* image_rgba, const int32_t* hits, const uint64_t* rng) {
   auto&  p = m->parts[(size_t)i];
@@ -231,30 +255,10 @@ void download_part(vpt_multi* m, int i, float* image_rgba, int32_t* hits, uint64
     hits[px] = p.h_hits[s];
     rng[2 * (size_t)px] = p.h_rng[2 * s], rng[2 * (size_t)px + 1] = p.h_rng[2 * s + 1];
   }
+  p.mirror_sum = part_checksum(p, image_rgba, hits, rng), p.mirrored = true;
 }
 
-// 64 pixels spread over the frame (a fixed multiplicative sequence): what is stored there now
-void take_probes(vpt_multi* m, const float* image_rgba, const int32_t* hits, const uint64_t* rng) {
-  size_t pixels = (size_t)m->width * m->height;
-  m->probes.resize(64);
-  uint64_t x = 0x9e3779b97f4a7c15ull;
-  for (auto& pb : m->probes) {
-    x = x * 6364136223846793005ull + 1442695040888963407ull;
-    pb.pixel = (size_t)((x >> 20) % pixels);
-    memcpy(pb.image, image_rgba + 4 * pb.pixel, 16);
-    pb.hits = hits[pb.pixel];
-    pb.rng[0] = rng[2 * pb.pixel], pb.rng[1] = rng[2 * pb.pixel + 1];
-  }
-}
-bool probes_match(const vpt_multi* m, const float* image_rgba, const int32_t* hits, const uint64_t* rng) {
-  if (m->probes.empty()) return false;
-  for (auto& pb : m->probes)
-    if (memcmp(pb.image, image_rgba + 4 * pb.pixel, 16) != 0 || pb.hits != hits[pb.pixel] || pb.rng[0] != rng[2 * pb.pixel] ||
-        pb.rng[1] != rng[2 * pb.pixel + 1])
-      return false;
-  return true;
-}
-bool always_upload() {   // VPT_MULTI_RESIDENT=0: every host-pointer call uploads the caller's arrays (no probe)
+bool always_upload() {   // VPT_MULTI_RESIDENT=0: every host-pointer call uploads the caller's arrays (no checksum pass)
   const char* e = getenv("VPT_MULTI_RESIDENT");
   return e && !strcmp(e, "0");
 }
@@ -323,7 +327,7 @@ int vpt_multi_set_state(vpt_multi* m, int width, int height, const float* image_
   if (!m || !image_rgba || !hits || !rng) return vpt_set_error(VPT_ERR_INVALID_ARG, "null argument");
   if (width <= 0 || height <= 0 || samples < 0) return vpt_set_error(VPT_ERR_INVALID_ARG, "bad image size or sample count");
   if (int rc = size_for(m, width, height)) return rc;
-  m->resident = false, m->probes.clear();
+  m->resident = false, forget_mirror(m);
   int rc = fan_out(m, [&](int i) {
     upload_part(m, i, image_rgba, hits, rng);
     auto& p = m->parts[(size_t)i];
@@ -337,8 +341,9 @@ int vpt_multi_set_state(vpt_multi* m, int width, int height, const float* image_
 int vpt_multi_get_state(vpt_multi* m, float* image_rgba, int32_t* hits, uint64_t* rng, int* samples) {
   if (!m || !image_rgba || !hits || !rng) return vpt_set_error(VPT_ERR_INVALID_ARG, "null argument");
   if (!m->resident) return vpt_set_error(VPT_ERR_INVALID_ARG, "no state on the devices");
+  forget_mirror(m);
   if (int rc = fan_out(m, [&](int i) { download_part(m, i, image_rgba, hits, rng); })) return rc;
-  take_probes(m, image_rgba, hits, rng);
+  m->mirror_image = image_rgba, m->mirror_hits = hits, m->mirror_rng = rng;
   if (samples) *samples = m->samples;
   return VPT_OK;
 }
@@ -356,18 +361,23 @@ int vpt_multi_render(vpt_multi* m, const vpt_params* params, int nsamples, int w
   if (nsamples < todo) todo = nsamples;
   if (todo <= 0) return VPT_OK;
   const int ndev = (int)m->parts.size();
-  // the caller's arrays are uploaded unless they are the state this handle stored there after its last render
-  const bool upload = !on_device && !(m->resident && !always_upload() && m->width == width && m->height == height && m->samples == *samples_io &&
-                                      m->samples > 0 && probes_match(m, image_rgba, hits, rng));
-  if (upload) {
+  // The caller's arrays are the state, as in the reference: every part of them is uploaded unless the device provably holds it
+  // already - the arrays are the very ones (same addresses, same size, same sample count) the last call downloaded into, and
+  // the part's checksum over all of its words, re-taken now by the device's thread, is what that download stored.
+  const bool may_skip = !on_device && m->resident && !always_upload() && m->width == width && m->height == height && m->samples == *samples_io &&
+                        m->samples > 0 && m->mirror_image == image_rgba && m->mirror_hits == hits && m->mirror_rng == rng;
+  if (!on_device && !may_skip) {
     if (int rc = size_for(m, width, height)) return rc;
-    m->resident = false, m->probes.clear();
+    m->resident = false, forget_mirror(m);
   }
   int rc = fan_out(m, [&](int i) {
     auto& p = m->parts[(size_t)i];
-    if (upload) {
+    p.uploaded = false;
+    if (!on_device && !(may_skip && p.mirrored && part_checksum(p, image_rgba, hits, rng) == p.mirror_sum)) {
+      p.mirrored = false;
       upload_part(m, i, image_rgba, hits, rng);
       if (p.rc != VPT_OK) return;
+      p.uploaded = true;
     }
     HIP_OK(hipSetDevice(p.device), p);
     vpt_layout lay = {width, height, 8, 8, i, ndev};
@@ -381,13 +391,23 @@ int vpt_multi_render(vpt_multi* m, const vpt_params* params, int nsamples, int w
     if (int r = vpt_check_watchdog(p.scene)) p.rc = r, p.error = vpt_last_error();   // a wave of the implicit kernel gave up: incomplete image
   });
   if (rc != VPT_OK) {
-    m->resident = false, m->probes.clear();   // some devices may have advanced, others not
+    m->resident = false, forget_mirror(m);   // some devices may have advanced, others not
     return rc;
   }
   *samples_io += todo;
   m->samples = *samples_io, m->resident = true;
-  if (!on_device) take_probes(m, image_rgba, hits, rng);
+  if (!on_device) m->mirror_image = image_rgba, m->mirror_hits = hits, m->mirror_rng = rng;   // download_part took the checksums
+  else forget_mirror(m);   // the devices moved on; no host array mirrors them
   return VPT_OK;
+}
+
+// parts of the last vpt_multi_render call with host pointers that were uploaded (0 ... device count): lets a caller - and
+// the tests - see what the residency check decided
+int vpt_multi_uploaded_parts(const vpt_multi* m) {
+  int n = 0;
+  if (m)
+    for (auto& p : m->parts) n += p.uploaded;
+  return n;
 }
 
 int vpt_multi_get_render(vpt_multi* m, float* image_rgba) {

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cctype>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -441,7 +442,9 @@ void skip_ws(const char*& p, const char* end) {
 bool parse_float(const char*& p, const char* end, float& v) {   // correctly rounded like the reference's fast_float
   skip_ws(p, end);
   if (p >= end) return false;
-  auto tmp = string(p, (size_t)std::min<ptrdiff_t>(end - p, 63));
+  auto q = p;   // the whole token, however long: a capped copy would split one long literal into two numbers
+  while (q < end && !isspace((unsigned char)*q)) q++;
+  auto tmp = string(p, (size_t)(q - p));
   auto stop = (char*)nullptr;
   v = std::strtof(tmp.c_str(), &stop);
   if (stop == tmp.c_str()) return false;
@@ -455,6 +458,7 @@ bool parse_int(const char*& p, const char* end, int& v) {
   auto stop = (char*)nullptr;
   v = (int)std::strtol(tmp.c_str(), &stop, 10);
   if (stop == tmp.c_str()) return false;
+  if (stop == tmp.c_str() + 31) return false;   // an index that fills the whole 31-character window: not an OBJ index, and its tail would be read as the next one
   p += stop - tmp.c_str();
   return true;
 }
@@ -630,6 +634,15 @@ bool load_subdiv(const string& filename, subdiv_data& subdiv, string& error) {
     subdiv.positions = obj.positions, subdiv.normals = obj.normals, subdiv.texcoords = obj.texcoords;
     for (auto& uv : subdiv.texcoords) uv.y = 1 - uv.y;
     subdiv.quadspos.clear(), subdiv.quadsnorm.clear(), subdiv.quadstexcoord.clear();
+    // A cage that mixes faces with line / point elements is REJECTED, a deliberate divergence: the reference's get_fvquads
+    // (yocto_modelio.cpp:2446) skips such an element WITHOUT advancing its vertex cursor, so every later face reads the
+    // wrong vertices (a defect no test scene of the reference exercises: none of its cages holds l / p statements); there is
+    // no fixture to pin either behaviour to, so the file is refused rather than rendered differently from the reference.
+    for (auto& e : obj.elements)
+      if (e.etype != 'f') {
+        error = filename + ": line / point elements in a subdivision cage are not supported";
+        return false;
+      }
     // get_fvquads (yocto_modelio.cpp:2435-2488): which index kinds exist is decided by the FIRST vertex of the file
     if (!obj.vertices.empty()) {
       obj_fan_quads(obj, subdiv.quadspos, [](const obj_vertex& v) { return v.position; });

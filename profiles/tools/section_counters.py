@@ -19,13 +19,14 @@ t0 = time.perf_counter()
 dev.pathtrace_samples(st, p, spp)
 dt = time.perf_counter() - t0
 lib.vpt_debug_counts(out, 0)
-names = ['node step', 'prim test', 'instance entry', 'outer iteration', 'trip (query)', 'pop', 'miss', 'surface', 'volume', 'lights', 'generate', 'leaf']
+names = ['node step', 'prim test', 'instance entry', 'outer iteration', 'trip (query)', 'pop', 'miss', 'surface', 'volume', 'lights', 'generate', 'leaf',
+         'session (lanes = rays handed over)', 'session node step (lanes = 4 x rays)', 'session leaf step (lanes = 4 x rays)']
 nsamp = st.width * st.height * spp
 slots = nsamp / 64
-print(f"{'section':20s} {'wave-exec/sample-slot':>22s} {'lane-exec/sample':>18s} {'avg lanes':>10s}")
+print(f"{'section':52s} {'wave-exec/sample-slot':>22s} {'lane-exec/sample':>18s} {'avg lanes':>10s}")
 for k, n in enumerate(names):
     w, l = out[2 * k], out[2 * k + 1]
-    if w: print(f"{n:20s} {w / slots:22.2f} {l / nsamp:18.2f} {l / w:10.1f}")
+    if w: print(f"{n:52s} {w / slots:22.2f} {l / nsamp:18.2f} {l / w:10.1f}")
 
 tn = ['A node loops', 'B prim phases', 'C instance entry', 'whole query', 'trip', 'lights pdf loop + MIS', 'sample_lights', 'surface event', 'volume event', 'generate', 'kernel', 'light CDF search', 'scatter eval (bsdf/phase)', 'medium distance sampling', 'surface: position+normal+material', 'surface: delta lobe']
 tot = out[32 + 10]

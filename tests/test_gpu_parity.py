@@ -36,7 +36,7 @@ from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-def _check_against_reference(oracle, scene, params, spp, g, ref_img, ref_rng, name, min_same, min_ok, min_stable, pixels=None):
+def _check_against_reference(oracle, scene, params, spp, g, ref_img, ref_rng, name, min_same, min_ok, min_stable, pixels=None, deep_rounds=2048):
     """the strict check of the module docstring; g = device state, ref_* = the reference's state.
     pixels: row-major indices of the pixels the reference state holds (a seeded sample of a full-size frame): the check and
     its shares are over those pixels only"""
@@ -54,7 +54,7 @@ def _check_against_reference(oracle, scene, params, spp, g, ref_img, ref_rng, na
     left = np.flatnonzero((chosen & stable & ~ok).reshape(-1))      # disagreeing pixels the 16 frame-wide patterns did not move
     deep = 0
     if 0 < len(left) <= 64:                                          # stage 2: 2048 more patterns on those pixels only
-        d_stream, d_rad = oracle.unstable_pixels(scene, params, spp, ref_img, ref_rng, fresh, rounds=2048, pixels=left, first_seed=1000)
+        d_stream, d_rad = oracle.unstable_pixels(scene, params, spp, ref_img, ref_rng, fresh, rounds=deep_rounds, pixels=left, first_seed=1000)
         deep = int((d_stream | d_rad).sum())
         stable &= ~(d_stream | d_rad)
     bad = chosen & stable & ~ok
@@ -224,8 +224,10 @@ LONG_CHAIN = {  # configs 3 and 4 at their full frame, 256 samples of a pixel's 
     # A pixel's stream survives 256 samples only if none of its ~700 (head) / ~1 500 (sdf) libm-dependent decisions flips, so the
     # identical-stream share is lower than at 4 spp by construction; what the strict check demands is unchanged: a pixel may differ
     # only where the reference's own value moves under 1-ulp libm nudges.
-    "config3_05_head_1280x256": ("05_head1ss_sub/head1ss_sub.json", "volpathtrace", 1280, 64, (1280, 1280), 256, (0.90, 0.90, 0.50)),
-    "config4_06_gridsdf_1280x256": ("06_gridsdf_full/gridsdf_full.json", "implicit", 1280, 4, (1280, 533), 256, (0.60, 0.55, 0.30)),
+    # (scene, shader, resolution, bounces, (w, h), spp, pixels, floors); the voxel scene's oracle does 0.1 Msamples/s on the sampled pixels,
+    # so its case holds 1 024 of them and its second stage 128 patterns: the case stays within two minutes of host time
+    "config3_05_head_1280x256": ("05_head1ss_sub/head1ss_sub.json", "volpathtrace", 1280, 64, (1280, 1280), 256, 4096, (0.998, 0.997, 0.99)),   # measured 0.9998 0.9995 0.9978 (gpurun_out/r4a)
+    "config4_06_gridsdf_1280x256": ("06_gridsdf_full/gridsdf_full.json", "implicit", 1280, 4, (1280, 533), 256, 1024, (0.60, 0.55, 0.30)),
 }
 
 
@@ -233,7 +235,7 @@ LONG_CHAIN = {  # configs 3 and 4 at their full frame, 256 samples of a pixel's 
 def test_long_chains_on_the_big_scenes(vpt, oracle, name):
     """256 samples per pixel on the 144 046-triangle scene (K1, overflow-stack instance) and on the 96^3 + 64^3 voxel scene (K2):
     the full frame on the device in one call, the oracle on a seeded sample of 4 096 of its pixels, the strict per-pixel check."""
-    scene_file, shader, res, bounces, size, spp, floors = LONG_CHAIN[name]
+    scene_file, shader, res, bounces, size, spp, npix, floors = LONG_CHAIN[name]
     scene = vpt.HostScene(os.path.join(GOLDEN, "scenes", scene_file))
     dev = vpt.DeviceScene(scene, 0)
     q = vpt.PathtraceParams(resolution=res, samples=spp, shader=shader, bounces=bounces)
@@ -242,9 +244,11 @@ def test_long_chains_on_the_big_scenes(vpt, oracle, name):
     assert (g.width, g.height, g.samples) == (*size, spp)
     assert (g.hits == spp).all() and np.isfinite(g.image).all()
     pix = _sampled_pixels(size)
+    pix = pix[:: max(1, len(pix) // npix)][:npix]
+    print(f"{name}: device frame done, oracle on {len(pix)} pixels x {spp} spp ...", flush=True)
     ref = scene.make_state(q)
     oracle.oracle_render(scene, q, ref, spp, nthreads=0, pixels=pix)
-    _check_against_reference(oracle, scene, q, spp, g, ref.image, ref.rngs, name + f" {size[0]}x{size[1]}x{spp}", *floors, pixels=pix)
+    _check_against_reference(oracle, scene, q, spp, g, ref.image, ref.rngs, name + f" {size[0]}x{size[1]}x{spp}", *floors, pixels=pix, deep_rounds=128)
 
 
 def _rms_vs_check(vpt, state, check_name):
@@ -392,9 +396,22 @@ def test_intersect_is_bit_identical_on_edge_case_rays(vpt, oracle, scene_file, l
     scene = vpt.HostScene(os.path.join(GOLDEN, "scenes", scene_file))
     dev = vpt.DeviceScene(scene, 0)
     rays = _edge_rays(np.random.default_rng(7), lo, hi, 40000)
-    for instance in (-1, 0):
-        ids, uvt = dev.intersect(rays, instance)
-        rids, ruvt = oracle.oracle_intersect(scene, rays, instance)
-        assert (ids[:, 0] >= 0).mean() > 0.05   # the batch does hit things
-        assert np.array_equal(ids, rids), np.nonzero((ids != rids).any(axis=1))[0][:10]
-        assert np.array_equal(uvt.view(np.uint32), ruvt.view(np.uint32)), np.nonzero((uvt.view(np.uint32) != ruvt.view(np.uint32)).any(axis=1))[0][:10]
+    # The traversal has two forms (vpt_mesh_kernel.hip.h): a lane walks its own ray while more than 16 rays of its wave need node or
+    # leaf work, and sets of up to 16 rays run in "sessions" on four lanes each.  Dense waves (64 rays) start in the first form
+    # and drain into the second; the sparse batches keep 12 / 3 / 1 real rays per wave (the other lanes hold rays that miss the scene's
+    # box and finish at once), so that sessions carry those rays from their first node on.
+    far = np.float32([1e3, 1e3, 1e3, 0.57735027, 0.57735027, 0.57735027])
+    lane = np.arange(len(rays)) % 64
+    batches = [("dense", rays)]
+    for keep, name in ((12, "12 per wave"), (3, "3 per wave"), (1, "1 per wave")):
+        sparse = rays.copy()
+        sparse[(lane * 7 + 3) % 64 >= keep] = far
+        batches.append((name, sparse))
+    for name, batch in batches:
+        for instance in (-1, 0):
+            ids, uvt = dev.intersect(batch, instance)
+            rids, ruvt = oracle.oracle_intersect(scene, batch, instance)
+            if name == "dense":
+                assert (ids[:, 0] >= 0).mean() > 0.05   # the batch does hit things
+            assert np.array_equal(ids, rids), (name, instance, np.nonzero((ids != rids).any(axis=1))[0][:10])
+            assert np.array_equal(uvt.view(np.uint32), ruvt.view(np.uint32)), (name, instance, np.nonzero((uvt.view(np.uint32) != ruvt.view(np.uint32)).any(axis=1))[0][:10])

@@ -73,8 +73,10 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_intersect_k
   extern __shared__ int lds_stack[];
   const lane_stack2<SPILL> stk = make_lane_stack<SPILL>(lds_stack, stack);
   int i = blockIdx.x * VPT_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  hit_t h = traverse(sc, mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]), instance, stk);
+  const bool live = i < n;   // the whole wave goes through the query (traverse(): the group forms need every lane); surplus lanes carry no ray
+  if (!live) i = 0;
+  hit_t h = traverse(sc, live, mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]), instance, stk);
+  if (!live) return;
   ids[2 * i] = h.hit ? h.instance : -1, ids[2 * i + 1] = h.hit ? h.element : -1;
   uvt[3 * i] = h.hit ? h.uv.x : 0, uvt[3 * i + 1] = h.hit ? h.uv.y : 0, uvt[3 * i + 2] = h.hit ? h.distance : 0;
 }
@@ -593,7 +595,8 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
     float4* e = &enter[6 * (size_t)k];
     e[0] = in.inv[0], e[1] = in.inv[1], e[2] = in.inv[2];
     e[3] = make_float4(sh.root_box[0], sh.root_box[1], sh.root_box[2], sh.root_box[3]);
-    int tail[6] = {sh.root_ref, sh.wnode_offset, sh.leaf_offset, id, in.translation_only, sh.num_nodes};
+    // the quad nodes of all BVHs live in one array, the scene's first: a level is named by the index of its first node
+    int tail[6] = {sh.root_ref, (int)(scene_wnodes.size() / 8) + sh.wnode_offset, sh.leaf_offset, id, in.translation_only, sh.num_nodes};
     e[4] = make_float4(sh.root_box[4], sh.root_box[5], 0, 0);
     memcpy(&e[4].z, &tail[0], 8);
     memcpy(&e[5], &tail[2], 16);
@@ -620,8 +623,14 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   leafs.resize(leafs.size() + 8, make_float4(0, 0, 0, 0));   // phase B fetches one record ahead of the one it tests
   UP(upload(s, leafs, &D.leaf_prims));
   UP(upload(s, leaf_attrs, &D.leaf_attrs));
-  UP(upload(s, scene_wnodes, &D.scene_wnodes));
-  UP(upload(s, shape_wnodes, &D.shape_wnodes));
+  {
+    const size_t scene_count = scene_wnodes.size();
+    if ((scene_count + shape_wnodes.size()) / 8 >= (1ull << 27)) return fail(VPT_ERR_UNSUPPORTED, "more than 2^27 quad nodes");
+    std::vector<float4> wnodes = scene_wnodes;   // one allocation: [scene quad nodes][shape quad nodes]
+    wnodes.insert(wnodes.end(), shape_wnodes.begin(), shape_wnodes.end());
+    UP(upload(s, wnodes, &D.scene_wnodes));
+    D.shape_wnodes = D.scene_wnodes + scene_count;
+  }
   UP(upload(s, enter, &D.scene_enter));
   UP(upload(s, slot_of, &D.slot_of_instance));
   UP(upload(s, instances, &D.instances));

@@ -80,12 +80,12 @@ struct DScene {
   // boxes and child references, so a visit costs one fetch and culled children are never fetched.
   //   q0 = {L.min.xyz, L.max.x} q1 = {L.max.yz, R.min.xy} q2 = {R.min.z, R.max.xyz}
   //   q3 = {ref0, ref1, axis, -} (ints); ref >= 0: internal wide node; ref < 0: leaf, ~ref = start<<4 | num
-  const float4* scene_wnodes;
-  const float4* shape_wnodes;
+  const float4* scene_wnodes;   // ONE array: the scene's quad nodes, then the shapes' (traverse() names a level by its first node's index)
+  const float4* shape_wnodes;   // = scene_wnodes + 8 * (number of scene quad nodes)
   // "enter records": everything the traversal needs to enter the instance stored at a scene-BVH
   // primitive slot, in one 96-byte gather instead of the prims[] -> instances[] -> shapes[] chain:
   //   e0..e2 = inverse frame (packed), e3 = {root lo.xyz, root hi.x}, e4 = {root hi.y, root hi.z,
-  //   root_ref, wnode_offset}, e5 = {leaf_offset, instance id, translation_only, num_nodes} (ints)
+  //   root_ref, first quad node of the shape in scene_wnodes}, e5 = {leaf_offset, instance id, translation_only, num_nodes} (ints)
   const float4* scene_enter;      // 6 per scene-BVH primitive slot
   const int*    slot_of_instance; // instance id -> slot (single-instance queries)
   int   scene_root_ref, pad1;

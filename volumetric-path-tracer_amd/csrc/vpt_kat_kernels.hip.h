@@ -10,25 +10,27 @@ VPT_DEV void kat_put3(float* o, f3 v) { o[0] = v.x, o[1] = v.y, o[2] = v.z; }
 
 // sample_lights_pdf as K1 evaluates it (vpt_mesh_kernel.hip.h, `advance_lights`): light records, inline walks of
 // single-leaf mesh lights, quad-node hops for emissive meshes with a real BVH
+// (every lane of the wave calls this, `live` = the lane holds a record: the hops go through traverse() as a whole wave)
 template <class STK>
-VPT_DEV float kat_lights_pdf_k1(const DScene& sc, f3 position, f3 direction, int maxiter, const STK& stk) {
+VPT_DEV float kat_lights_pdf_k1(const DScene& sc, bool live, f3 position, f3 direction, int maxiter, const STK& stk) {
   float sum = 0;
   for (int l = 0; l < sc.num_lights; l++) {
     float4 r6 = sc.light_rec[8 * l + 6], r7 = sc.light_rec[8 * l + 7];
-    int    kind = __float_as_int(r7.w) & 255;
+    int    kind = __builtin_amdgcn_readfirstlane(__float_as_int(r7.w) & 255);   // the same light for every lane
     if (kind == VPT_LIGHT_SMALL_MESH) {
-      sum += small_light_pdf(sc, l, r6, r7, position, direction);
+      if (live) sum += small_light_pdf(sc, l, r6, r7, position, direction);
     } else if (kind == VPT_LIGHT_LARGE_MESH) {
       float cur = 0;
       f3    pos = position;
-      for (int hop = 0; hop < 100; hop++) {
-        hit_t h = traverse(sc, pos, direction, sc.lights[l].instance, stk);
-        if (!h.hit) break;
-        cur += large_light_hop(sc, l, h, position, direction, pos);
+      bool  walking = live;
+      for (int hop = 0; hop < 100 && __builtin_amdgcn_ballot_w64(walking) != 0; hop++) {
+        hit_t h = traverse(sc, walking, pos, direction, sc.lights[l].instance, stk);
+        if (walking && !h.hit) walking = false;
+        if (walking) cur += large_light_hop(sc, l, h, position, direction, pos);
       }
       sum += cur;
     } else {
-      sum += other_light_pdf(sc, l, kind, r6, position, direction, maxiter);
+      if (live) sum += other_light_pdf(sc, l, kind, r6, position, direction, maxiter);
     }
   }
   return sum * ((float)1 / (float)sc.num_lights);
@@ -42,7 +44,23 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_kat_kernel(
   lane_stack stk2;                                                             // binary-node traversal (K2's light walk)
   stk2.base = lds_stack + threadIdx.x, stk2.cap = stack_cap;
   int i = blockIdx.x * VPT_BLOCK + threadIdx.x;
-  if (i >= n) return;
+  const bool live = i < n;
+  // the two ops that run BVH queries keep the whole wave together (traverse(): the group forms need every lane); `op` is the same for all lanes
+  if (op == VPT_KAT_INTERSECT || op == VPT_KAT_LIGHTS_PDF) {
+    const float* a = in + (long long)(live ? i : 0) * si;
+    float*       o = out + (long long)(live ? i : 0) * so;
+    if (op == VPT_KAT_INTERSECT) {
+      hit_t h = traverse(sc, live, ld3(a), ld3(a + 3), (int)a[6], stk4);
+      if (!live) return;
+      o[0] = h.hit ? (float)h.instance : -1.0f, o[1] = h.hit ? (float)h.element : -1.0f;
+      o[2] = h.hit ? h.uv.x : 0, o[3] = h.hit ? h.uv.y : 0, o[4] = h.hit ? h.distance : 0;
+    } else {
+      float pdf = kat_lights_pdf_k1(sc, live, ld3(a), ld3(a + 3), iparam, stk4);
+      if (live) o[0] = pdf;
+    }
+    return;
+  }
+  if (!live) return;
   const float* a = in + (long long)i * si;
   float*       o = out + (long long)i * so;
   for (int k = 0; k < so; k++) o[k] = 0;
@@ -86,11 +104,6 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_kat_kernel(
       ray_t ray = eval_camera(sc.cameras[(int)a[0]], mk2(a[1], a[2]), mk2(a[3], a[4]));
       kat_put3(o, ray.o), kat_put3(o + 3, ray.d);
     } break;
-    case VPT_KAT_INTERSECT: {
-      hit_t h = traverse(sc, ld3(a), ld3(a + 3), (int)a[6], stk4);
-      o[0] = h.hit ? (float)h.instance : -1.0f, o[1] = h.hit ? (float)h.element : -1.0f;
-      o[2] = h.hit ? h.uv.x : 0, o[3] = h.hit ? h.uv.y : 0, o[4] = h.hit ? h.distance : 0;
-    } break;
     case VPT_KAT_SURFACE: {
       const DInstance& inst = sc.instances[(int)a[0]];
       f3     position, normal;
@@ -105,7 +118,6 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_kat_kernel(
     } break;
     case VPT_KAT_ENVIRONMENT: kat_put3(o, eval_environment(sc, ld3(a))); break;
     case VPT_KAT_SAMPLE_LIGHTS: kat_put3(o, sample_lights(sc, ld3(a), a[3], a[4], mk2(a[5], a[6]))); break;
-    case VPT_KAT_LIGHTS_PDF: o[0] = kat_lights_pdf_k1(sc, ld3(a), ld3(a + 3), iparam, stk4); break;
     case VPT_KAT_LIGHTS_PDF_K2: o[0] = lights_pdf_k2(sc, ld3(a), ld3(a + 3), iparam, stk2); break;
     case VPT_KAT_SDF_SCENE: {
       sdf_hit r = eval_sdf_scene(sc, scene_sdf_recs(sc), ld3(a), a[3]);

@@ -66,13 +66,43 @@ struct lane_stack2 {
   static constexpr bool spills = SPILL;
   VPT_DEV void pop(int& sp, int& ref, float& t0) const {
     sp--;
-    if (!SPILL || sp < cap) ref = base[(2 * sp) * VPT_BLOCK], t0 = __int_as_float(base[(2 * sp + 1) * VPT_BLOCK]);
+    load(sp, ref, t0);
+  }
+  // entry `pos`, wherever it lives
+  VPT_DEV void store(int pos, int ref, float t0) const {
+    if (!SPILL || pos < cap) put(pos, ref, t0);
+    else deep[(pos - cap) * lanes] = make_int2(ref, __float_as_int(t0));
+  }
+  VPT_DEV void load(int pos, int& ref, float& t0) const {
+    if (!SPILL || pos < cap) ref = base[(2 * pos) * VPT_BLOCK], t0 = __int_as_float(base[(2 * pos + 1) * VPT_BLOCK]);
     else {
-      int2 e = deep[(sp - cap) * lanes];
+      int2 e = deep[(pos - cap) * lanes];
       ref = e.x, t0 = __int_as_float(e.y);
     }
   }
+  // the stack of another lane of this wave (the helper lanes of a group form work on their ray owner's column)
+  VPT_DEV lane_stack2 of_lane(int lane) const {
+    lane_stack2 s = *this;
+    s.base = base + (lane - (int)threadIdx.x), s.deep = deep + (lane - (int)threadIdx.x);
+    return s;
+  }
 };
+
+// ---- cross-lane moves (traverse(): the group forms).  DPP and ds_bpermute deliver 0 from a lane that is switched off, so
+// these are only used where every lane they read is known to be active: inside group_nodes() / group_leaves(), which run only when the whole
+// wave is in the call (exec = all ones), on groups of four lanes that are switched on and off together.
+VPT_DEV int quad_lane0(int v) { return __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true); }   // quad_perm [0,0,0,0]
+VPT_DEV int quad_xor1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xb1, 0xf, 0xf, true); }    // quad_perm [1,0,3,2]
+VPT_DEV int quad_xor2(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4e, 0xf, 0xf, true); }    // quad_perm [2,3,0,1]
+VPT_DEV int quad_or(int v) {
+  v |= quad_xor1(v);
+  v |= quad_xor2(v);
+  return v;
+}
+VPT_DEV int   pull(int lane, int v) { return __builtin_amdgcn_ds_bpermute(lane << 2, v); }
+VPT_DEV float pull(int lane, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(lane << 2, __float_as_int(v))); }
+VPT_DEV f3    pull(int lane, f3 v) { return mk3(pull(lane, v.x), pull(lane, v.y), pull(lane, v.z)); }
+VPT_DEV int   lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
 template <bool SPILL>
 VPT_DEV lane_stack2<SPILL> make_lane_stack(int* lds, const stack_cfg& cfg) {
   lane_stack2<SPILL> stk;
@@ -125,35 +155,66 @@ VPT_DEV bool slab_pass_signed(float nx, float ny, float nz, float fx, float fy, 
 // One BVH query.  only_instance < 0: intersect_bvh(bvh, scene, ray) (yocto_bvh.cpp:800-871);
 // only_instance >= 0: intersect_bvh(bvh, scene, instance, ray) (:874-881).  Ray = {wo, wd, 1e-4, flt_max}.
 //
-// Loop shape: the lane's next action is kept in `cur` (>= 0: quad node of the current level,
-// VPT_NONE: nothing left at this level, other negatives: a leaf).  Each trip of the outer loop runs up
-// to three phases, each entered only by the lanes that need it, so unlike work is never interleaved
-// inside one loop body:
-//   A  quad nodes: fetch, four box tests, descend into the first-visited passing child directly (it would
-//      be popped next with the same tmax, so its pop test is a tautology) and push the others, last first;
+// EVERY lane of the wave that is in the surrounding code calls this, with `active` = "this lane has a ray": a lane without one
+// (its path ended, its pixel is finished, it owns no pixel) lends its registers and issue slots to the others' rays (the group
+// forms, below).  The function is correct from any control flow; the group forms only run when the whole wave is in the call.
+//
+// Per-lane ("own") form.  The lane's next action is kept in `cur` (>= 0: quad node of the current level, VPT_NONE: nothing
+// left at this level, other negatives: a leaf).  Three kinds of work, never interleaved in one loop body:
+//   A  quad nodes: fetch, four box tests, descend into the first-visited passing child directly (it would be popped next
+//      with the same tmax, so its pop test is a tautology) and push the others, last first;
 //   B  shape leaf: primitive tests in order;
-//   C  scene leaf / pending instances: transform the ray, test the instance's root box (the test the
-//      reference's shape-level loop does first, yocto_bvh.cpp:728-733); instances that miss it are
-//      skipped without ever leaving world space.
+//   C  scene leaf / pending instances: transform the ray, test the instance's root box (the test the reference's shape-level
+//      loop does first, yocto_bvh.cpp:728-733); instances that miss it are skipped without ever leaving world space.
+//
+// GROUP FORMS of A and B (round 4).  In the own form a node step runs with 9.8 of 64 lanes switched on and a primitive test with
+// 12.2 (profiles/r01_v8_section_counters.txt): the lanes of a wave need different kinds of work at different times, and most node
+// steps belong to the tail of a query, when a handful of long rays is left.  Whenever at most VPT_COOP_MAX (16) rays of the wave are
+// in a phase, the phase runs on groups of FOUR lanes per ray - ray k of the set on lanes 4k .. 4k+3, whoever owns those lanes; the
+// ray's state travels there by ds_bpermute and its results back - with the SAME loop shape as the own form (phase A until no ray of
+// the set holds a node, then phase B once), so the wave takes the same number of steps, each a fraction of the work:
+//   A  lane c of a group loads and tests grandchild c of the quad node (8 dwords and ~25 instructions instead of 29 dwords and
+//      ~75); the reference's visit order is a 2-bit rank per lane computed from the three split axes and the ray's signs, the
+//      four (pass, rank) pairs meet by DPP quad_perm, each lane stores its own candidate into the OWNER's LDS stack column
+//      at the position its rank gives it, and the first-visited one becomes the group's next node;
+//   B  the (<= 4) primitives of a leaf are tested one per lane against the tmax at leaf entry and reduced to the reference's
+//      winner: the smallest t, on an exact tie the later primitive (intersect_triangle only rejects t > tmax,
+//      yocto_geometry.h:786-819, and the leaf loop overwrites, yocto_bvh.cpp:770-789; a primitive's t does not depend on
+//      tmax, only its acceptance does, so min-then-last is what the sequential loop leaves behind).  A NaN distance (a
+//      degenerate triangle met by a ray with a zero component) makes every later comparison in the reference true: a group
+//      that meets one, or holds a NaN tmax, reports nothing and its owner walks the leaf in the own form.
+// Per-box and per-primitive arithmetic is the own form's, operand for operand: the bits are the same (tests: KAT intersect_*,
+// test_intersect_is_bit_identical_on_edge_case_rays with dense and with sparse waves, every whole-path case).
+// Measured (03_volume, 1280x533x256 spp): 254.0 -> 227.0 ms per launch.  A first version kept a ray in its group across phases until it
+// needed C work ("sessions"): fewer transfers, but the rays outside a session waited for its longest member - 174 wave-level node
+// steps per 64 samples against the own form's 132 - and it LOST (276 ms, profiles/r04_k1_group_forms.txt).
 #define VPT_NONE (-2147483647 - 1)
 #ifndef VPT_HOIST_MAX
 #define VPT_HOIST_MAX 16   // scenes with at most this many instances test all root boxes at the start of a query
 #endif
+#ifndef VPT_COOP_MAX
+#define VPT_COOP_MAX 16    // a phase with at most this many rays runs in its group form (four lanes per ray); 0: own forms only
+#endif
+#ifdef VPT_TRAVERSE_GUARD
+__device__ unsigned g_vpt_guard_trips;   // diagnostic build: queries that were cut short after VPT_TRAVERSE_GUARD loop rounds (must stay 0)
+#endif
 template <class STK>
-VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const STK& stk) {
+VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_instance, const STK& stk) {
   hit_t r;
   r.instance = -1, r.element = -1, r.uv = mk2(0, 0), r.distance = 0, r.hit = false, r.prim = 0;
   const float tmin = VPT_RAY_EPS;
   float tmax = VPT_FLT_MAX;
-  const f3   winv = rcp3_exact(wd);
+  const bool whole_wave = __builtin_amdgcn_ballot_w64(true) == ~0ull;   // the group forms move data between lanes: all of them have to be here
+  // (a lane without a ray holds whatever its last ray left in wo / wd: it must not steer the wave-wide choices of the reciprocal and slab forms)
+  const f3   winv = rcp3_exact(active ? wd : mk3(1, 1, 1));
   const int  wsgn = sign_bits(winv);
-  const bool wslow = nan_prone(wd, winv);
+  const bool wslow = active && nan_prone(wd, winv);
   f3    co = wo, cd = wd, cinv = winv;
   int   csgn = wsgn;
   bool  slow = wslow;
   int   sp = 0, shape_base = -1, pend = 0, cur_inst = -1, cur = VPT_NONE;
-  const float4* wn    = sc.scene_wnodes;
-  const float4* leafs = sc.leaf_prims;
+  int   wnb = 0, leafb = 0;   // the current level's quad nodes start at sc.scene_wnodes[8 * wnb], its leaf records at sc.leaf_prims[4 * leafb]
+  bool  done = !active;
 
   // pop entries of the current level until one passes the reference's pop-time box test
   auto pop_valid = [&]() {
@@ -195,8 +256,7 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
       if (__float_as_int(e5.w) && box_test(slow, mk3(e3.x, e3.y, e3.z), mk3(e3.w, e4.x, e4.y), co, cinv, tmin, tmax, t0)) {
         if (general) csgn = sign_bits(cinv);
         cur_inst = __float_as_int(e5.y), shape_base = sp;
-        wn    = sc.shape_wnodes + 8 * (long long)__float_as_int(e4.w);
-        leafs = sc.leaf_prims + 4 * (long long)__float_as_int(e5.x);
+        wnb = __float_as_int(e4.w), leafb = __float_as_int(e5.x);
         return __float_as_int(e4.z);   // the instance's root: visited next with the same tmax
       }
       if (general) cd = wd, cinv = winv, slow = wslow;
@@ -205,162 +265,322 @@ VPT_DEV hit_t traverse(const DScene& sc, f3 wo, f3 wd, int only_instance, const 
     return pop_valid();
   };
 
-  if (only_instance < 0) {
-    float t0;
-    if (sc.num_scene_nodes && box_test(slow, mk3(sc.scene_root_lo_x, sc.scene_root_lo_y, sc.scene_root_lo_z),
-                                  mk3(sc.scene_root_hi_x, sc.scene_root_hi_y, sc.scene_root_hi_z), co, cinv, tmin, tmax, t0))
-      cur = sc.scene_root_ref;
-    // Small scenes: every lane tests the root boxes of ALL instances now, in lockstep (the slot index is
-    // wave-uniform: scalar record loads, no divergence), with tmax = inf.  A box missed with tmax = inf is missed
-    // with any tmax (t1 = min(far, tmax) * k only shrinks), so phase C skips those instances without fetching
-    // their records; the others are tested again there against the current tmax, as the reference does.
-    // Entering instances one lane at a time is the most divergent part of a query (13 of 64 lanes active).
-    if (sc.num_scene_prims <= VPT_HOIST_MAX && cur != VPT_NONE) {
-      bool any_slow = __builtin_amdgcn_ballot_w64(wslow) != 0;
-      reach = 0;
-      for (int s = 0; s < sc.num_scene_prims; s++) {
-        const float4* e = sc.scene_enter + 6 * s;
-        float4 e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5];
-        // the record is the same for every lane: branch on its flags as scalars, each arm complete in itself
-        int  translation = __builtin_amdgcn_readfirstlane(__float_as_int(e5.z));
-        int  has_root    = __builtin_amdgcn_readfirstlane(__float_as_int(e5.w));
-        if (!has_root) continue;
-        f3    blo = mk3(e3.x, e3.y, e3.z), bhi = mk3(e3.w, e4.x, e4.y);
-        float t0;
-        bool  pass;
-        if (translation && !any_slow) {
-          pass = box_pass_fast(blo, bhi, mk3(wo.x + e2.y, wo.y + e2.z, wo.z + e2.w), winv, tmin, VPT_FLT_MAX, t0);
-        } else {
-          frame inv  = unpack_frame(e[0], e[1], e2);
-          f3    ld   = transform_vector(inv, wd);
-          f3    linv = rcp3_exact(ld);
-          pass = box_test(nan_prone(ld, linv), blo, bhi, transform_point(inv, wo), linv, tmin, VPT_FLT_MAX, t0);
+  if (active) {
+    if (only_instance < 0) {
+      float t0;
+      if (sc.num_scene_nodes && box_test(slow, mk3(sc.scene_root_lo_x, sc.scene_root_lo_y, sc.scene_root_lo_z),
+                                    mk3(sc.scene_root_hi_x, sc.scene_root_hi_y, sc.scene_root_hi_z), co, cinv, tmin, tmax, t0))
+        cur = sc.scene_root_ref;
+      // Small scenes: every lane tests the root boxes of ALL instances now, in lockstep (the slot index is
+      // wave-uniform: scalar record loads, no divergence), with tmax = inf.  A box missed with tmax = inf is missed
+      // with any tmax (t1 = min(far, tmax) * k only shrinks), so phase C skips those instances without fetching
+      // their records; the others are tested again there against the current tmax, as the reference does.
+      // Entering instances one lane at a time is the most divergent part of a query (13 of 64 lanes active).
+      if (sc.num_scene_prims <= VPT_HOIST_MAX && cur != VPT_NONE) {
+        bool any_slow = __builtin_amdgcn_ballot_w64(wslow) != 0;
+        reach = 0;
+        for (int s = 0; s < sc.num_scene_prims; s++) {
+          const float4* e = sc.scene_enter + 6 * s;
+          float4 e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5];
+          // the record is the same for every lane: branch on its flags as scalars, each arm complete in itself
+          int  translation = __builtin_amdgcn_readfirstlane(__float_as_int(e5.z));
+          int  has_root    = __builtin_amdgcn_readfirstlane(__float_as_int(e5.w));
+          if (!has_root) continue;
+          f3    blo = mk3(e3.x, e3.y, e3.z), bhi = mk3(e3.w, e4.x, e4.y);
+          float t0;
+          bool  pass;
+          if (translation && !any_slow) {
+            pass = box_pass_fast(blo, bhi, mk3(wo.x + e2.y, wo.y + e2.z, wo.z + e2.w), winv, tmin, VPT_FLT_MAX, t0);
+          } else {
+            frame inv  = unpack_frame(e[0], e[1], e2);
+            f3    ld   = transform_vector(inv, wd);
+            f3    linv = rcp3_exact(ld);
+            pass = box_test(nan_prone(ld, linv), blo, bhi, transform_point(inv, wo), linv, tmin, VPT_FLT_MAX, t0);
+          }
+          if (pass) reach |= 1u << s;
         }
-        if (pass) reach |= 1u << s;
+      }
+      if (cur == VPT_NONE) done = true;   // the ray misses the scene's box
+    } else {   // single-instance query (yocto_bvh.cpp:874-881)
+      pend = (sc.slot_of_instance[only_instance] << 4) | 1;
+      cur  = enter_pending();
+      shape_base = 0;
+      if (cur == VPT_NONE) done = true;
+    }
+  }
+
+  // ---- own form of A: one quad-node step of this lane's ray ------------------------------------------------------------
+  auto own_node_step = [&]() {
+    VPT_CNT(CNT_NODE);
+    const float4* q = sc.scene_wnodes + 8 * (long long)(wnb + cur);
+    // rows of the node: lo.x lo.y lo.z hi.x hi.y hi.z (four children each).  The near plane of an axis is
+    // the lo row for a positive direction, the hi row for a negative one: fetch them by the ray's signs
+    int    ix = (csgn & 1) ? 3 : 0, iy = (csgn & 2) ? 4 : 1, iz = (csgn & 4) ? 5 : 2;
+    float4 nx = q[ix], fx = q[3 - ix], ny = q[iy], fy = q[5 - iy], nz = q[iz], fz = q[7 - iz], qr = q[6];
+    int    meta = __float_as_int(q[7].x);
+    float4 anx = make_float4((nx.x - co.x) * cinv.x, (nx.y - co.x) * cinv.x, (nx.z - co.x) * cinv.x, (nx.w - co.x) * cinv.x);
+    float4 afx = make_float4((fx.x - co.x) * cinv.x, (fx.y - co.x) * cinv.x, (fx.z - co.x) * cinv.x, (fx.w - co.x) * cinv.x);
+    float4 any = make_float4((ny.x - co.y) * cinv.y, (ny.y - co.y) * cinv.y, (ny.z - co.y) * cinv.y, (ny.w - co.y) * cinv.y);
+    float4 afy = make_float4((fy.x - co.y) * cinv.y, (fy.y - co.y) * cinv.y, (fy.z - co.y) * cinv.y, (fy.w - co.y) * cinv.y);
+    float4 anz = make_float4((nz.x - co.z) * cinv.z, (nz.y - co.z) * cinv.z, (nz.z - co.z) * cinv.z, (nz.w - co.z) * cinv.z);
+    float4 afz = make_float4((fz.x - co.z) * cinv.z, (fz.y - co.z) * cinv.z, (fz.z - co.z) * cinv.z, (fz.w - co.z) * cinv.z);
+    float  t0, t1, t2, t3;
+    bool   p0, p1, p2, p3;
+    if (__builtin_amdgcn_ballot_w64(slow) != 0) {   // some lane may meet 0 * inf: the reference's NaN-asymmetric form for all
+      // (lo - o) * inv and (hi - o) * inv are the same products, told apart again by the sign
+      bool sx = csgn & 1, sy = csgn & 2, sz = csgn & 4;
+      p0 = slab_pass(mk3(sx ? afx.x : anx.x, sy ? afy.x : any.x, sz ? afz.x : anz.x), mk3(sx ? anx.x : afx.x, sy ? any.x : afy.x, sz ? anz.x : afz.x), tmin, tmax, t0);
+      p1 = slab_pass(mk3(sx ? afx.y : anx.y, sy ? afy.y : any.y, sz ? afz.y : anz.y), mk3(sx ? anx.y : afx.y, sy ? any.y : afy.y, sz ? anz.y : afz.y), tmin, tmax, t1);
+      p2 = slab_pass(mk3(sx ? afx.z : anx.z, sy ? afy.z : any.z, sz ? afz.z : anz.z), mk3(sx ? anx.z : afx.z, sy ? any.z : afy.z, sz ? anz.z : afz.z), tmin, tmax, t2);
+      p3 = slab_pass(mk3(sx ? afx.w : anx.w, sy ? afy.w : any.w, sz ? afz.w : anz.w), mk3(sx ? anx.w : afx.w, sy ? any.w : afy.w, sz ? anz.w : afz.w), tmin, tmax, t3);
+    } else {
+      p0 = slab_pass_signed(anx.x, any.x, anz.x, afx.x, afy.x, afz.x, tmin, tmax, t0);
+      p1 = slab_pass_signed(anx.y, any.y, anz.y, afx.y, afy.y, afz.y, tmin, tmax, t1);
+      p2 = slab_pass_signed(anx.z, any.z, anz.z, afx.z, afy.z, afz.z, tmin, tmax, t2);
+      p3 = slab_pass_signed(anx.w, any.w, anz.w, afx.w, afy.w, afz.w, tmin, tmax, t3);
+    }
+    // slots 0,1 = children of child 0, slots 2,3 = children of child 1 of the binary node.  The reference
+    // pushes child 0 then child 1 when the ray is negative along the node's axis (child 1 popped first),
+    // and does the same one level down when that child is popped: visit order = [group][member].
+    int  r0 = p0 ? __float_as_int(qr.x) : VPT_NONE, r1 = p1 ? __float_as_int(qr.y) : VPT_NONE;
+    int  r2 = p2 ? __float_as_int(qr.z) : VPT_NONE, r3 = p3 ? __float_as_int(qr.w) : VPT_NONE;
+    bool gn = (csgn >> (meta & 3)) & 1, g0 = (csgn >> ((meta >> 2) & 3)) & 1, g1 = (csgn >> ((meta >> 4) & 3)) & 1;
+    int   a0 = g0 ? r1 : r0, a1 = g0 ? r0 : r1, b0 = g1 ? r3 : r2, b1 = g1 ? r2 : r3;
+    float s0 = g0 ? t1 : t0, s1 = g0 ? t0 : t1, u0 = g1 ? t3 : t2, u1 = g1 ? t2 : t3;
+    int   v0 = gn ? b0 : a0, v1 = gn ? b1 : a1, v2 = gn ? a0 : b0, v3 = gn ? a1 : b1;
+    float w0 = gn ? u0 : s0, w1 = gn ? u1 : s1, w2 = gn ? s0 : u0, w3 = gn ? s1 : u1;
+    // push the later-visited ones (last first); the first-visited one is taken directly: it would be
+    // popped next with the same tmax, so its pop test is a tautology
+    int next;
+    if constexpr (!STK::spills) {
+      // branch-free: every candidate is stored; one that is not pushed lands on the free entry above the new
+      // top (the host sizes the LDS part one entry larger than the worst case)
+      bool f0 = v0 != VPT_NONE, f1 = v1 != VPT_NONE, f2 = v2 != VPT_NONE, f3 = v3 != VPT_NONE;
+      bool q3 = f3 && (f2 || f1 || f0), q2 = f2 && (f1 || f0), q1 = f1 && f0;
+      int  top = sp + (int)q3 + (int)q2 + (int)q1;
+      stk.put(q3 ? sp : top, v3, w3);
+      stk.put(q2 ? sp + (int)q3 : top, v2, w2);
+      stk.put(q1 ? sp + (int)q3 + (int)q2 : top, v1, w1);
+      sp   = top;
+      next = f0 ? v0 : f1 ? v1 : f2 ? v2 : v3;
+    } else {
+      float nt = w3;
+      next     = v3;
+      if (v2 != VPT_NONE) {
+        if (next != VPT_NONE) stk.push(sp, next, nt);
+        next = v2, nt = w2;
+      }
+      if (v1 != VPT_NONE) {
+        if (next != VPT_NONE) stk.push(sp, next, nt);
+        next = v1, nt = w1;
+      }
+      if (v0 != VPT_NONE) {
+        if (next != VPT_NONE) stk.push(sp, next, nt);
+        next = v0;
       }
     }
-  } else {   // single-instance query (yocto_bvh.cpp:874-881)
-    pend = (sc.slot_of_instance[only_instance] << 4) | 1;
-    cur  = enter_pending();
-    shape_base = 0;
-  }
+    cur = next != VPT_NONE ? next : pop_valid();
+  };
+
+  // ---- own form of B: the primitives of the shape leaf `cur`, in order ---------------------------------------------------
+  auto own_leaf = [&]() {
+    int code = ~cur, start = code >> 4, num = code & 15;
+    VPT_CNT(CNT_LEAF);
+    // software-pipelined: the next primitive's record is in flight while this one is tested (a leaf's
+    // records are contiguous; one past the last primitive of the pool is still inside the padded array)
+    const float4* rec = sc.leaf_prims + 4 * (long long)(leafb + start);
+    float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+    for (int k = 0; k < num; k++) {
+      VPT_CNT(CNT_PRIM);
+      float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+      rec += 4;
+      n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+      if (intersect_quad(co, cd, tmin, tmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), r.uv, r.distance))
+        r.hit = true, r.element = __float_as_int(r0.w), r.instance = cur_inst, tmax = r.distance, r.prim = leafb + start + k;
+    }
+    cur = pop_valid();
+  };
+
+#ifdef VPT_TRAVERSE_GUARD
+  int guard = 0;
+#endif
+  // ---- phase A of a small set: the rays of the lanes in `m` (at most 16, each on a quad node) on four lanes each, until every one of
+  // them holds a leaf or nothing (the loop the own form runs lane by lane: same steps, same order, a quarter of the work per lane) ----
+  auto group_nodes = [&](unsigned long long m) {
+    VPT_CNT_MASK(CNT_SESSION, m);   // "lanes" of this counter = rays handed over
+    const int  lane = threadIdx.x, j = lane & 3;
+    const bool mine = (m >> lane) & 1;
+    const int  rank = lanes_below(m), n = __popcll(m);
+    // ray k of the set (the k-th set bit of m) goes to lanes 4k .. 4k+3: its owner posts its lane number to lane 4k (lanes without a
+    // ray post to lane 1, which nobody reads), the group's other lanes copy it
+    int        owner = quad_lane0(__builtin_amdgcn_ds_permute(mine ? rank << 4 : 4, lane));
+    const bool gact  = (lane >> 2) < n;
+    if (!gact) owner = lane;
+    const f3    gco = pull(owner, co), gcinv = pull(owner, cinv);
+    const float gtmax = pull(owner, tmax);
+    int         gcur = pull(owner, cur), gsp = pull(owner, sp);
+    const int   gwnb = pull(owner, wnb);
+    const int   gmisc = pull(owner, (shape_base >= 0 ? shape_base : 0) | csgn << 8 | (slow ? 2048 : 0));
+    if (!gact) gcur = VPT_NONE;
+    const int  gfloor = gmisc & 255, gcsgn = (gmisc >> 8) & 7;   // pop floor of the ray's level, sign bits of its direction
+    const bool gslow = (gmisc & 2048) != 0;                      // NaN-prone direction
+    const STK  gstk = stk.of_lane(owner);
+    while (__builtin_amdgcn_ballot_w64(gcur >= 0) != 0) {
+      VPT_CNT_MASK(CNT_GNODE, __builtin_amdgcn_ballot_w64(gcur >= 0));
+#ifdef VPT_TRAVERSE_GUARD
+      if (++guard > VPT_TRAVERSE_GUARD) gcur = VPT_NONE;   // (the outer loop reports it)
+#endif
+      if (gcur >= 0) {
+        const float* q = (const float*)(sc.scene_wnodes + 8 * (long long)(gwnb + gcur));
+        float lox = q[j], loy = q[4 + j], loz = q[8 + j], hix = q[12 + j], hiy = q[16 + j], hiz = q[20 + j];
+        int   ref = __float_as_int(q[24 + j]), meta = __float_as_int(q[28]);
+        float ax = (lox - gco.x) * gcinv.x, ay = (loy - gco.y) * gcinv.y, az = (loz - gco.z) * gcinv.z;
+        float bx = (hix - gco.x) * gcinv.x, by = (hiy - gco.y) * gcinv.y, bz = (hiz - gco.z) * gcinv.z;
+        float t0;
+        bool  pass;
+        if (__builtin_amdgcn_ballot_w64(gslow) != 0) pass = slab_pass(mk3(ax, ay, az), mk3(bx, by, bz), tmin, gtmax, t0);   // the reference's form
+        else {   // no product can be NaN: min / max of the two products per axis in any association (as slab_pass_signed)
+          t0       = hw_max3(hw_max(hw_min(ax, bx), hw_min(ay, by)), hw_min(az, bz), tmin);
+          float t1 = hw_min3(hw_min(hw_max(ax, bx), hw_max(ay, by)), hw_max(az, bz), gtmax) * VPT_BOX_K;
+          pass     = t0 <= t1;
+        }
+        const int  rj = pass ? ref : VPT_NONE;   // an empty slot holds VPT_NONE itself
+        const bool present = rj != VPT_NONE;
+        // visit rank of grandchild j in the reference's order [group by the node's axis][member by the child's axis]
+        const int gn = (gcsgn >> (meta & 3)) & 1, g0 = (gcsgn >> ((meta >> 2) & 3)) & 1, g1 = (gcsgn >> ((meta >> 4) & 3)) & 1;
+        const int grp = j >> 1;
+        const int k = ((grp ^ gn) << 1) | ((j & 1) ^ (grp ? g1 : g0));
+        const int pv = quad_or(present ? 1 << k : 0);              // passing children by visit rank
+        const int kfirst = pv ? __builtin_ctz(pv) : 4;
+        // the first-visited one is the next node (popped next with the same tmax: its pop test is a tautology); the others are
+        // pushed last-visited first: rank k lands above the passing ranks greater than k
+        if (present && k > kfirst) gstk.store(gsp + __builtin_popcount(pv >> (k + 1)), rj, t0);
+        const int next = quad_or(present && k == kfirst ? rj : 0);
+        gsp += pv ? __builtin_popcount(pv) - 1 : 0;
+        gcur = next;
+        if (!pv) {   // pop_valid on the owner's column; the four lanes of a group read the same entries
+          gcur = VPT_NONE;
+          while (gsp > gfloor) {
+            int   pref;
+            float pt0;
+            gsp--;
+            gstk.load(gsp, pref, pt0);
+            if (pt0 <= gtmax * VPT_BOX_K) {
+              gcur = pref;
+              break;
+            }
+          }
+        }
+      }
+    }
+    // hand back: the owner of ray k reads lane 4k
+    const int src = mine ? rank << 2 : 0;
+    const int ncur = pull(src, gcur), nsp = pull(src, gsp);
+    if (mine) cur = ncur, sp = nsp;
+  };
+
+  // ---- phase B of a small set: the rays of the lanes in `m` (at most 16, each on a shape leaf): the (<= 4) primitives of a leaf one per
+  // lane of the ray's group.  Returns true for a lane whose leaf is still to be walked in the own form (a NaN met: see the file header) ----
+  auto group_leaves = [&](unsigned long long m) {
+    const int  lane = threadIdx.x, j = lane & 3;
+    const bool mine = (m >> lane) & 1;
+    const int  rank = lanes_below(m), n = __popcll(m);
+    int        owner = quad_lane0(__builtin_amdgcn_ds_permute(mine ? rank << 4 : 4, lane));
+    const bool gact  = (lane >> 2) < n;
+    if (!gact) owner = lane;
+    VPT_CNT_MASK(CNT_GLEAF, m);
+    const f3 gco = pull(owner, co), gcd = pull(owner, cd);
+    float    gtmax = pull(owner, tmax);
+    const int gcode = pull(owner, ~cur), gleafb = pull(owner, leafb);
+    const int start = gcode >> 4, num = gact ? gcode & 15 : 0;
+    bool  ghit = false, bad = gact && gtmax != gtmax;
+    float gu = 0, gv = 0;
+    int   gelem = 0, gprim = 0;
+    const int rounds = __builtin_amdgcn_ballot_w64(num > 4) != 0 ? 4 : 1;   // the reference's leaves hold <= 4 primitives; the format allows 15
+    for (int b = 0; b < 4 * rounds; b += 4) {
+      f2    uv = mk2(0, 0);
+      float t = 0;
+      bool  hit = false;
+      int   elem = 0;
+      if (b + j < num && !bad) {
+        const float4* rec = sc.leaf_prims + 4 * (long long)(gleafb + start + b + j);
+        float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        hit  = intersect_quad(gco, gcd, tmin, gtmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), uv, t);
+        elem = __float_as_int(r0.w);
+      }
+      bad = bad || quad_or(hit && t != t ? 1 : 0) != 0;
+      // smallest t of the four, on a tie the later primitive (a hit's t is finite: t <= tmax <= flt_max)
+      float key = hit && !bad ? t : __builtin_inff();
+      int   idx = j;
+      float ok = __int_as_float(quad_xor1(__float_as_int(key)));
+      int   oi = quad_xor1(idx);
+      bool  take = ok < key || (ok == key && oi > idx);
+      key = take ? ok : key, idx = take ? oi : idx;
+      ok = __int_as_float(quad_xor2(__float_as_int(key))), oi = quad_xor2(idx);
+      take = ok < key || (ok == key && oi > idx);
+      key = take ? ok : key, idx = take ? oi : idx;
+      const bool win = j == idx && key < __builtin_inff();
+      const int  wu = quad_or(win ? __float_as_int(uv.x) : 0), wv = quad_or(win ? __float_as_int(uv.y) : 0), we = quad_or(win ? elem : 0);
+      if (key < __builtin_inff()) ghit = true, gtmax = key, gu = __int_as_float(wu), gv = __int_as_float(wv), gelem = we, gprim = gleafb + start + b + idx;
+    }
+    // hand back: the owner of ray k reads lane 4k.  A group that met a NaN reports nothing: its owner walks the whole leaf itself
+    const int src = mine ? rank << 2 : 0;
+    const int nflag = pull(src, (ghit ? 1 : 0) | (bad ? 2 : 0));
+    const float nt = pull(src, gtmax), nu = pull(src, gu), nv = pull(src, gv);
+    const int   ne = pull(src, gelem), np = pull(src, gprim);
+    if (mine && nflag == 1) r.hit = true, r.distance = nt, tmax = nt, r.uv = mk2(nu, nv), r.element = ne, r.prim = np, r.instance = cur_inst;
+    return mine && (nflag & 2) != 0;
+  };
 
   while (true) {
     VPT_CNT(CNT_OUTER);
-    // ---- phase A: internal (quad) nodes ----------------------------------------------------------------
-    VPT_T0(TM_NODES);
-    while (cur >= 0) {
-      VPT_CNT(CNT_NODE);
-      const float4* q = wn + 8 * (long long)cur;
-      // rows of the node: lo.x lo.y lo.z hi.x hi.y hi.z (four children each).  The near plane of an axis is
-      // the lo row for a positive direction, the hi row for a negative one: fetch them by the ray's signs
-      int    ix = (csgn & 1) ? 3 : 0, iy = (csgn & 2) ? 4 : 1, iz = (csgn & 4) ? 5 : 2;
-      float4 nx = q[ix], fx = q[3 - ix], ny = q[iy], fy = q[5 - iy], nz = q[iz], fz = q[7 - iz], qr = q[6];
-      int    meta = __float_as_int(q[7].x);
-      float4 anx = make_float4((nx.x - co.x) * cinv.x, (nx.y - co.x) * cinv.x, (nx.z - co.x) * cinv.x, (nx.w - co.x) * cinv.x);
-      float4 afx = make_float4((fx.x - co.x) * cinv.x, (fx.y - co.x) * cinv.x, (fx.z - co.x) * cinv.x, (fx.w - co.x) * cinv.x);
-      float4 any = make_float4((ny.x - co.y) * cinv.y, (ny.y - co.y) * cinv.y, (ny.z - co.y) * cinv.y, (ny.w - co.y) * cinv.y);
-      float4 afy = make_float4((fy.x - co.y) * cinv.y, (fy.y - co.y) * cinv.y, (fy.z - co.y) * cinv.y, (fy.w - co.y) * cinv.y);
-      float4 anz = make_float4((nz.x - co.z) * cinv.z, (nz.y - co.z) * cinv.z, (nz.z - co.z) * cinv.z, (nz.w - co.z) * cinv.z);
-      float4 afz = make_float4((fz.x - co.z) * cinv.z, (fz.y - co.z) * cinv.z, (fz.z - co.z) * cinv.z, (fz.w - co.z) * cinv.z);
-      float  t0, t1, t2, t3;
-      bool   p0, p1, p2, p3;
-      if (__builtin_amdgcn_ballot_w64(slow) != 0) {   // some lane may meet 0 * inf: the reference's NaN-asymmetric form for all
-        // (lo - o) * inv and (hi - o) * inv are the same products, told apart again by the sign
-        bool sx = csgn & 1, sy = csgn & 2, sz = csgn & 4;
-        p0 = slab_pass(mk3(sx ? afx.x : anx.x, sy ? afy.x : any.x, sz ? afz.x : anz.x), mk3(sx ? anx.x : afx.x, sy ? any.x : afy.x, sz ? anz.x : afz.x), tmin, tmax, t0);
-        p1 = slab_pass(mk3(sx ? afx.y : anx.y, sy ? afy.y : any.y, sz ? afz.y : anz.y), mk3(sx ? anx.y : afx.y, sy ? any.y : afy.y, sz ? anz.y : afz.y), tmin, tmax, t1);
-        p2 = slab_pass(mk3(sx ? afx.z : anx.z, sy ? afy.z : any.z, sz ? afz.z : anz.z), mk3(sx ? anx.z : afx.z, sy ? any.z : afy.z, sz ? anz.z : afz.z), tmin, tmax, t2);
-        p3 = slab_pass(mk3(sx ? afx.w : anx.w, sy ? afy.w : any.w, sz ? afz.w : anz.w), mk3(sx ? anx.w : afx.w, sy ? any.w : afy.w, sz ? anz.w : afz.w), tmin, tmax, t3);
-      } else {
-        p0 = slab_pass_signed(anx.x, any.x, anz.x, afx.x, afy.x, afz.x, tmin, tmax, t0);
-        p1 = slab_pass_signed(anx.y, any.y, anz.y, afx.y, afy.y, afz.y, tmin, tmax, t1);
-        p2 = slab_pass_signed(anx.z, any.z, anz.z, afx.z, afy.z, afz.z, tmin, tmax, t2);
-        p3 = slab_pass_signed(anx.w, any.w, anz.w, afx.w, afy.w, afz.w, tmin, tmax, t3);
-      }
-      // slots 0,1 = children of child 0, slots 2,3 = children of child 1 of the binary node.  The reference
-      // pushes child 0 then child 1 when the ray is negative along the node's axis (child 1 popped first),
-      // and does the same one level down when that child is popped: visit order = [group][member].
-      int  r0 = p0 ? __float_as_int(qr.x) : VPT_NONE, r1 = p1 ? __float_as_int(qr.y) : VPT_NONE;
-      int  r2 = p2 ? __float_as_int(qr.z) : VPT_NONE, r3 = p3 ? __float_as_int(qr.w) : VPT_NONE;
-      bool gn = (csgn >> (meta & 3)) & 1, g0 = (csgn >> ((meta >> 2) & 3)) & 1, g1 = (csgn >> ((meta >> 4) & 3)) & 1;
-      int   a0 = g0 ? r1 : r0, a1 = g0 ? r0 : r1, b0 = g1 ? r3 : r2, b1 = g1 ? r2 : r3;
-      float s0 = g0 ? t1 : t0, s1 = g0 ? t0 : t1, u0 = g1 ? t3 : t2, u1 = g1 ? t2 : t3;
-      int   v0 = gn ? b0 : a0, v1 = gn ? b1 : a1, v2 = gn ? a0 : b0, v3 = gn ? a1 : b1;
-      float w0 = gn ? u0 : s0, w1 = gn ? u1 : s1, w2 = gn ? s0 : u0, w3 = gn ? s1 : u1;
-      // push the later-visited ones (last first); the first-visited one is taken directly: it would be
-      // popped next with the same tmax, so its pop test is a tautology
-      int next;
-      if constexpr (!STK::spills) {
-        // branch-free: every candidate is stored; one that is not pushed lands on the free entry above the new
-        // top (the host sizes the LDS part one entry larger than the worst case)
-        bool f0 = v0 != VPT_NONE, f1 = v1 != VPT_NONE, f2 = v2 != VPT_NONE, f3 = v3 != VPT_NONE;
-        bool q3 = f3 && (f2 || f1 || f0), q2 = f2 && (f1 || f0), q1 = f1 && f0;
-        int  top = sp + (int)q3 + (int)q2 + (int)q1;
-        stk.put(q3 ? sp : top, v3, w3);
-        stk.put(q2 ? sp + (int)q3 : top, v2, w2);
-        stk.put(q1 ? sp + (int)q3 + (int)q2 : top, v1, w1);
-        sp   = top;
-        next = f0 ? v0 : f1 ? v1 : f2 ? v2 : v3;
-      } else {
-        float nt = w3;
-        next     = v3;
-        if (v2 != VPT_NONE) {
-          if (next != VPT_NONE) stk.push(sp, next, nt);
-          next = v2, nt = w2;
-        }
-        if (v1 != VPT_NONE) {
-          if (next != VPT_NONE) stk.push(sp, next, nt);
-          next = v1, nt = w1;
-        }
-        if (v0 != VPT_NONE) {
-          if (next != VPT_NONE) stk.push(sp, next, nt);
-          next = v0;
-        }
-      }
-      cur = next != VPT_NONE ? next : pop_valid();
+#ifdef VPT_TRAVERSE_GUARD
+    if (++guard > VPT_TRAVERSE_GUARD) {
+      if (!done) atomicAdd(&g_vpt_guard_trips, 1u);
+      break;
     }
-    VPT_T1(TM_NODES);
-    if (cur == VPT_NONE) {
-      if (shape_base < 0 || only_instance >= 0) break;   // nothing left: query finished
-      // leaving an instance: back to world space, then its leaf's next instance or the next scene entry
-      shape_base = -1;
-      cd = wd, cinv = winv, csgn = wsgn, slow = wslow;   // co: enter_pending
-      wn  = sc.scene_wnodes;
-      VPT_T0(TM_ENTER);
-      cur = enter_pending();
-      VPT_T1(TM_ENTER);
-      if (cur == VPT_NONE && shape_base < 0) break;
+#endif
+    // ---- A: quad nodes, until no lane holds one.  More than VPT_COOP_MAX rays: every lane steps its own; fewer: four lanes per ray ----------
+    VPT_T0(TM_NODES);
+    const unsigned long long ma = __builtin_amdgcn_ballot_w64(!done && cur >= 0);
+    if (ma != 0) {
+      if (VPT_COOP_MAX > 0 && whole_wave && __popcll(ma) <= VPT_COOP_MAX) group_nodes(ma);
+      else if (!done && cur >= 0) own_node_step();
+      VPT_T1(TM_NODES);
       continue;
     }
-    int code = ~cur;
-    if (shape_base >= 0) {
-      // ---- phase B: primitives of a shape leaf, in order -------------------------------------------------
-      int start = code >> 4, num = code & 15;
-      VPT_CNT(CNT_LEAF);
-      VPT_T0(TM_PRIMS);
-      // software-pipelined: the next primitive's record is in flight while this one is tested (a leaf's
-      // records are contiguous; one past the last primitive of the pool is still inside the padded array)
-      const float4* rec = leafs + 4 * (long long)start;
-      float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
-      for (int k = 0; k < num; k++) {
-        VPT_CNT(CNT_PRIM);
-        float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
-        rec += 4;
-        n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
-        if (intersect_quad(co, cd, tmin, tmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), r.uv, r.distance))
-          r.hit = true, r.element = __float_as_int(r0.w), r.instance = cur_inst, tmax = r.distance, r.prim = (int)((rec - sc.leaf_prims) >> 2) - 1;
+    VPT_T1(TM_NODES);
+    // ---- B: shape leaves --------------------------------------------------------------------------------------------------------------
+    VPT_T0(TM_PRIMS);
+    {
+      const bool at_leaf = !done && cur != VPT_NONE && shape_base >= 0;   // (cur < 0 for every lane here)
+      const unsigned long long mb = __builtin_amdgcn_ballot_w64(at_leaf);
+      bool own = at_leaf;
+      if (VPT_COOP_MAX > 0 && whole_wave && mb != 0 && __popcll(mb) <= VPT_COOP_MAX) {
+        own = group_leaves(mb);
+        if (at_leaf && !own) cur = pop_valid();
       }
-      cur = pop_valid();
-      VPT_T1(TM_PRIMS);
-    } else {
-      // ---- phase C: a scene leaf: its instances are entered one after another, in order ---------------------
-      pend = code;
-      VPT_T0(TM_ENTER);
-      cur  = enter_pending();
-      VPT_T1(TM_ENTER);
-      if (cur == VPT_NONE && shape_base < 0) break;
+      if (own) own_leaf();
     }
+    VPT_T1(TM_PRIMS);
+    // ---- C: a level is exhausted or a scene leaf is reached ---------------------------------------------------------------------
+    VPT_T0(TM_ENTER);
+    if (!done && cur < 0 && (cur == VPT_NONE || shape_base < 0)) {
+      bool go = true;
+      if (cur == VPT_NONE) {
+        if (shape_base < 0 || only_instance >= 0) done = true, go = false;   // nothing left: query finished
+        else {   // leaving an instance: back to world space, then its leaf's next instance or the next scene entry
+          shape_base = -1, wnb = 0;
+          cd = wd, cinv = winv, csgn = wsgn, slow = wslow;   // co: enter_pending
+        }
+      } else pend = ~cur;   // a scene leaf: its instances are entered one after another, in order
+      if (go) {
+        cur = enter_pending();
+        if (cur == VPT_NONE && shape_base < 0) done = true;
+      }
+    }
+    VPT_T1(TM_ENTER);
+    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
   }
   return r;
 }
@@ -511,15 +731,19 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
   // Cold per-pixel state lives in LDS behind the stacks instead of in registers for the whole launch: the radiance sum
   // (touched once per sample) and the pixel's coordinates (once per sample) - five words per lane.
   float* const park = (float*)(lds_stack + stack.cap * 2 * VPT_BLOCK) + threadIdx.x;
+  // Lanes that own no pixel (padding slots of a ragged frame, the empty lanes of a split tile) stay in the kernel: the whole wave
+  // goes through every BVH query together, and a lane without a ray works on the others' rays there (traverse(): group forms)
+  bool owns;
   {
     int px0 = 0, py0 = 0;
-    if (slot < 0 || slot >= pr.nslots || !slot_to_pixel(pr, slot, px0, py0)) return;   // padding lanes own no pixel
+    owns = slot >= 0 && slot < pr.nslots && slot_to_pixel(pr, slot, px0, py0);
     park[4 * VPT_BLOCK] = __int_as_float(px0 | (py0 << 16));
+    if (!owns) slot = 0;
   }
 
-  float4     acc_in = image[slot];
+  float4     acc_in = owns ? image[slot] : make_float4(0, 0, 0, 0);
   park[0] = acc_in.x, park[VPT_BLOCK] = acc_in.y, park[2 * VPT_BLOCK] = acc_in.z, park[3 * VPT_BLOCK] = acc_in.w;
-  ulonglong2 r_in   = rngs[slot];
+  ulonglong2 r_in   = owns ? rngs[slot] : make_ulonglong2(0, 1);
   rng_t      rng    = {r_in.x, r_in.y};
   const int  nb     = (SH == K_EYELIGHT) ? max(pr.bounces, 4) : pr.bounces;
   constexpr bool HAS_MIS = (SH == K_VOLPATH || SH == K_PATH);
@@ -539,10 +763,12 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
   int   lp_light = 0, lp_hop = 0;
   bool  mis_toggle = false;
 
+  bool alive = owns;   // this lane's pixel still has samples to render
   VPT_T0(TM_KERNEL);
   while (true) {
-    if (state == ST_NEW) {
-      if (sample == pr.nsamples) break;
+    if (alive && state == ST_NEW && sample == pr.nsamples) alive = false;
+    if (__builtin_amdgcn_ballot_w64(alive) == 0) break;   // wave-uniform: every lane stays until the tile is finished
+    if (alive && state == ST_NEW) {
       VPT_CNT(CNT_GENERATE);
       VPT_T0(TM_GENERATE);
       const vpt_camera& cam = sc.cameras[pr.camera];
@@ -564,17 +790,16 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
       VPT_T1(TM_GENERATE);
     }
 
-    bool finish = false;
-    if (state == ST_MAIN && SH != K_DEBUG && bounce >= nb) {
-      finish = true;
-    } else {
-      // ---- the one BVH query of this trip ---------------------------------------------------------
+    // ---- the one BVH query of this trip: the whole wave is in the call, lanes without a ray as helpers ---------------
+    const bool query = alive && !(state == ST_MAIN && SH != K_DEBUG && bounce >= nb);
+    bool finish = alive && !query;   // the path ran out of bounces
+    const bool lpdf_query = HAS_LARGE && query && state == ST_LPDF;
+    const int  qinst      = lpdf_query ? sc.lights[lp_light].instance : -1;
+    VPT_T0(TM_QUERY);
+    hit_t h = traverse(sc, query, lpdf_query ? lp_pos : ray.o, ray.d, qinst, stk);
+    VPT_T1(TM_QUERY);
+    if (query) {
       VPT_CNT(CNT_TRIP);
-      bool  lpdf_query = HAS_LARGE && state == ST_LPDF;
-      int   qinst      = lpdf_query ? sc.lights[lp_light].instance : -1;
-      VPT_T0(TM_QUERY);
-      hit_t h          = traverse(sc, lpdf_query ? lp_pos : ray.o, ray.d, qinst, stk);
-      VPT_T1(TM_QUERY);
 
       bool advance_lights = false;   // continue the light-pdf walk at lp_light
       if (lpdf_query) {
@@ -793,12 +1018,14 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
   if ((threadIdx.x & 63) == 0)   // lane 0 owns a pixel whenever the wave does (padding lanes sit at the end)
     for (int k = 0; k < 16; k++) atomicAdd(&g_vpt_cnt[32 + k], s_vpt_time[k]);
 #endif
-  image[slot] = make_float4(park[0], park[VPT_BLOCK], park[2 * VPT_BLOCK], park[3 * VPT_BLOCK]);
-  hits[slot] += pr.nsamples;
-  ulonglong2 r_out;
-  r_out.x = rng.state, r_out.y = rng.inc;
-  rngs[slot] = r_out;
-  if (sched.cost && threadIdx.x == 0) {   // lane 0 (the tile's corner pixel) exists whenever the wave owns a pixel
+  if (owns) {
+    image[slot] = make_float4(park[0], park[VPT_BLOCK], park[2 * VPT_BLOCK], park[3 * VPT_BLOCK]);
+    hits[slot] += pr.nsamples;
+    ulonglong2 r_out;
+    r_out.x = rng.state, r_out.y = rng.inc;
+    rngs[slot] = r_out;
+  }
+  if (sched.cost && threadIdx.x == 0 && owns) {   // lane 0 (the tile's corner pixel) exists whenever the wave owns a pixel
     const unsigned long long wave_start = s_wave_start;
     unsigned long long dt = clock_ticks(slot) - wave_start;   // after the last sample was accumulated
     sched.cost[wave] = dt < 0xffffffffull ? (unsigned)dt : 0xffffffffu;

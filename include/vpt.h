@@ -389,6 +389,17 @@ typedef struct vpt_subdiv_level {
   int64_t        num_items;
 } vpt_subdiv_level;
 int vpt_subdivide_vertices(int device, const vpt_subdiv_level* level, const float* vertices, float* new_vertices);
+/* The rest of tesselate_surface's float work on the device (yocto_pathtrace.cpp:1239, 1256-1271), same ordered-list scheme, same bits:
+ * vpt_vertex_normals   quads_normals (corners = 4; a quad with z == w is a triangle and adds to three vertices) / triangles_normals
+ *                      (corners = 3) of yocto_shape.cpp:1478-1512: area-weighted face normals added per vertex IN FACE ORDER, normalised;
+ *                      positions / normals are float3 arrays, faces int4 / int3.  The per-vertex face lists are built on the host here.
+ * vpt_displace_vertices  new_positions = positions + normals * displacement * (mean(xyz(eval_texture(texture, uv, as_linear = true)))
+ *                      [- 0.5 for an 8-bit texture]) (cpp:1259-1265) through the render kernels' own eval_texture; `texels` is the
+ *                      texture's first texel (uchar4 or float4 by texture->is_float; texture->offset is ignored).
+ * Synchronous; indices are validated on the host before a kernel runs. */
+int vpt_vertex_normals(int device, int32_t num_vertices, const float* positions, int32_t num_faces, int32_t corners, const int32_t* faces, float* normals);
+int vpt_displace_vertices(int device, const vpt_texture* texture, const void* texels, float displacement, int32_t num_vertices,
+                          const float* positions, const float* normals, const float* texcoords, float* new_positions);
 
 /* Device self-test of an arithmetic shortcut the kernels rely on for bit-exact parity: the reference divides
  * (1 / d per ray, yocto_bvh.cpp:806-808; 1 / det per triangle, yocto_geometry.h:690), the kernels use

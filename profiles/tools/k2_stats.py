@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import vpt_loader  # noqa: E402
 
 NAMES = ("trips scene_rounds scene_lanes light_rounds light_lanes shade_rounds shade_lanes done_lanes wait_lanes_at_march "
-         "light_lanes_at_scene scene_lanes_at_shade clk_scene clk_light clk_shade clk_total").split()
+         "light_lanes_at_scene scene_lanes_at_shade clk_scene clk_light clk_shade clk_total scene_le8 scene_le16 scene_le32 scene_lanes_le16 scene_lanes_le32").split()
 
 
 def main():
@@ -22,7 +22,7 @@ def main():
     p = vpt.PathtraceParams(resolution=1280, samples=1 << 20, shader="implicit", bounces=4)
     st = scene.make_state(p)
     dev.pathtrace_samples(st, p, spp)          # first launch: tile order
-    out = (C.c_ulonglong * 16)()
+    out = (C.c_ulonglong * 24)()
     vpt.hip.vpt_debug_k2_stats(out, 1)
     dev.pathtrace_samples(st, p, spp)          # second launch: longest wave first
     vpt.hip.vpt_debug_k2_stats(out, 0)
@@ -37,6 +37,9 @@ def main():
           f"rest (prologue, state I/O, loop head) {1 - (v['clk_scene'] + v['clk_light'] + v['clk_shade']) / tot:.3f}")
     samples = st.width * st.height * spp
     print(f"per sample: scene rounds {v['scene_rounds'] * 8 / samples * 64:.1f} wave-steps x 64 lanes offered, {v['scene_lanes'] * 8 / samples:.1f} lane-steps used (upper bound: rounds hold up to 8 steps)")
+    sr = max(1, v["scene_rounds"])
+    print(f"scene rounds by marching lanes: <= 8: {v['scene_le8'] / sr:.3f}, <= 16: {v['scene_le16'] / sr:.3f} (holding {v['scene_lanes_le16'] / max(1, v['scene_lanes']):.3f} of the lane-steps), "
+          f"<= 32: {v['scene_le32'] / sr:.3f} ({v['scene_lanes_le32'] / max(1, v['scene_lanes']):.3f} of the lane-steps)")
     print(f"rounds: trips {v['trips']}, scene {v['scene_rounds']}, light {v['light_rounds']}, shade {v['shade_rounds']}")
 
 

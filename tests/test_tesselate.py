@@ -119,6 +119,27 @@ def test_catmullclark_levels_are_consistent(vpt):
         vpt.catmullclark(np.array([[0, 1, 2, 9]], np.int32), verts)
 
 
+def test_host_normals_and_displacement_stages(vpt):
+    """the single-stage entry points (host form) on meshes small enough to check by hand; the whole of tesselate_surfaces is pinned to the
+    reference by the hash tests above"""
+    pos = np.float32([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [2, 0, 1]])
+    n4 = vpt.vertex_normals(pos, np.int32([[0, 1, 2, 3]]))
+    assert np.array_equal(n4[:4], np.float32([[0, 0, 1]] * 4)) and np.array_equal(n4[4], np.float32([0, 0, 0]))   # an unused vertex keeps the zero vector
+    n3 = vpt.vertex_normals(pos, np.int32([[0, 1, 2], [1, 4, 2]]))
+    assert np.array_equal(n3[0], np.float32([0, 0, 1])) and abs(np.linalg.norm(n3[1]) - 1) < 1e-6 and n3[1][0] < 0     # vertex 1 blends both faces
+    tri_as_quad = vpt.vertex_normals(pos, np.int32([[0, 1, 2, 2]]))                                                    # z == w: three corners add, not four
+    assert np.array_equal(tri_as_quad[:3], np.float32([[0, 0, 1]] * 3))
+    with pytest.raises(vpt.VptError):
+        vpt.vertex_normals(pos, np.int32([[0, 1, 9]]))
+    tex = np.zeros((2, 2, 4), np.uint8)
+    tex[..., :3] = 255                                                                                                 # white, 8-bit: mean 1 - 0.5
+    out = vpt.displace_vertices(tex, False, 0.5, pos[:4], np.float32([[0, 0, 1]] * 4), np.float32([[0.1, 0.2]] * 4))
+    assert np.allclose(out, pos[:4] + np.float32([0, 0, 0.25]), rtol=0, atol=1e-6)   # the four bilinear weights sum to 1 within an ulp
+    texf = np.full((2, 2, 4), 0.5, np.float32)                                                                         # float texels: no offset
+    out = vpt.displace_vertices(texf, True, 2.0, pos[:4], np.float32([[0, 0, 1]] * 4), np.float32([[0.6, 0.7]] * 4))
+    assert np.allclose(out, pos[:4] + np.float32([0, 0, 1.0]), rtol=0, atol=1e-6)
+
+
 def _random_mesh(rng, n):
     """an n x n grid with holes, some cells split into two triangles, two cells welded into a bow tie"""
     idx = lambda x, y: y * (n + 1) + x
@@ -135,6 +156,31 @@ def _random_mesh(rng, n):
                 quads.append([a, b, c, d])
     verts = rng.normal(size=((n + 1) ** 2, 3)).astype(np.float32)
     return np.array(quads, np.int32), verts
+
+
+@pytest.mark.gpu
+def test_device_normals_and_displacement_equal_the_host_stages_bit_for_bit(vpt, dev03):
+    """vpt_vertex_normals / vpt_displace_vertices (csrc/vpt_subdiv.hip) against the host loops that the reference's hashes pin: same float bits
+    on random meshes with holes, triangles as z == w quads, a welded bow tie, shared and unused vertices; 8-bit sRGB, 8-bit linear and float
+    displacement textures, texture coordinates outside [0, 1) and on texel borders"""
+    rng = np.random.default_rng(11)
+    for n in (1, 3, 17, 60):
+        quads, verts = _random_mesh(rng, n)
+        if len(quads) == 0:
+            continue
+        verts = np.vstack([verts, rng.normal(size=(3, 3)).astype(np.float32)])                     # three vertices no face uses
+        hq, dq = vpt.vertex_normals(verts, quads), vpt.vertex_normals(verts, quads, device=0)
+        assert np.array_equal(hq.view(np.uint32), dq.view(np.uint32)), n
+        tris = np.array([[q[0], q[1], q[3]] for q in quads] + [[q[2], q[3], q[1]] for q in quads if q[2] != q[3]], np.int32)
+        ht, dt = vpt.vertex_normals(verts, tris), vpt.vertex_normals(verts, tris, device=0)
+        assert np.array_equal(ht.view(np.uint32), dt.view(np.uint32)), n
+        uv = rng.uniform(-1.5, 2.5, size=(len(verts), 2)).astype(np.float32)
+        uv[::7] = np.round(uv[::7] * 8) / 8                                                         # exactly on texel borders of the 8 x 4 textures
+        for texels, linear in ((rng.integers(0, 256, size=(4, 8, 4), dtype=np.uint8), False), (rng.integers(0, 256, size=(4, 8, 4), dtype=np.uint8), True),
+                               (rng.uniform(0, 2, size=(5, 3, 4)).astype(np.float32), True)):
+            hd = vpt.displace_vertices(texels, linear, 0.37, verts, ht, uv)
+            dd = vpt.displace_vertices(texels, linear, 0.37, verts, ht, uv, device=0)
+            assert np.array_equal(hd.view(np.uint32), dd.view(np.uint32)), (n, texels.dtype, linear)
 
 
 @pytest.mark.gpu

@@ -127,6 +127,8 @@ host.vpth_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
 host.vpth_scene_load.restype = _p
 host.vpth_scene_load_ex.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
 host.vpth_scene_load_ex.restype = _p
+host.vpth_vertex_normals.argtypes = [_p, C.c_int, _p, C.c_int, C.c_int, C.c_int, _p, C.c_char_p, C.c_int]
+host.vpth_displace_vertices.argtypes = [_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, _p, C.c_int, C.c_int, _p, C.c_char_p, C.c_int]
 host.vpth_catmullclark.argtypes = [_p, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, C.POINTER(C.c_int), _p, C.POINTER(C.c_int), C.c_char_p, C.c_int]
 host.vpth_scene_free.argtypes = [_p]
 host.vpth_scene_free.restype = None
@@ -185,6 +187,37 @@ def catmullclark(quads: np.ndarray, verts: np.ndarray, lock_boundary: bool = Fal
                               qo.ctypes.data, C.byref(nq), vo.ctypes.data, C.byref(nv), err, len(err)) != 0:
         raise VptError(err.value.decode())
     return qo[:nq.value].copy(), vo[:nv.value].copy()
+
+
+def vertex_normals(positions: np.ndarray, faces: np.ndarray, device: Optional[int] = None) -> np.ndarray:
+    """quads_normals ((n, 4) faces; z == w: a triangle) / triangles_normals ((n, 3)) of yocto_shape.cpp:1478-1512 over (m, 3) float32
+    positions: area-weighted face normals added per vertex in face order, normalised.  device: GPU index (vpt_vertex_normals)."""
+    positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    faces = np.ascontiguousarray(faces, np.int32)
+    out = np.zeros_like(positions)
+    err = C.create_string_buffer(512)
+    if host.vpth_vertex_normals(positions.ctypes.data, len(positions), faces.ctypes.data, len(faces), faces.shape[1], -1 if device is None else device,
+                                out.ctypes.data, err, len(err)) != 0:
+        raise VptError(err.value.decode())
+    return out
+
+
+def displace_vertices(texels: np.ndarray, linear: bool, displacement: float, positions: np.ndarray, normals: np.ndarray, texcoords: np.ndarray,
+                      device: Optional[int] = None) -> np.ndarray:
+    """the displacement step of tesselate_surface (yocto_pathtrace.cpp:1259-1265): positions + normals * displacement * (mean(rgb of
+    eval_texture(uv, as_linear)) [- 0.5 for uint8 texels]).  texels: (h, w, 4) uint8 or float32.  device: GPU index (vpt_displace_vertices)."""
+    texels = np.ascontiguousarray(texels)
+    assert texels.ndim == 3 and texels.shape[2] == 4 and texels.dtype in (np.uint8, np.float32)
+    positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    texcoords = np.ascontiguousarray(texcoords, np.float32).reshape(-1, 2)
+    out = np.zeros_like(positions)
+    err = C.create_string_buffer(512)
+    if host.vpth_displace_vertices(texels.ctypes.data, texels.shape[1], texels.shape[0], int(texels.dtype == np.float32), int(linear), C.c_float(displacement),
+                                   positions.ctypes.data, normals.ctypes.data, texcoords.ctypes.data, len(positions), -1 if device is None else device,
+                                   out.ctypes.data, err, len(err)) != 0:
+        raise VptError(err.value.decode())
+    return out
 
 
 class HostScene:

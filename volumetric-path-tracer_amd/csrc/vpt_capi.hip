@@ -1544,10 +1544,10 @@ int vpt_debug_wave_hw(unsigned* out, int nwaves) {
 
 #ifdef VPT_K2_STATS
 // diagnostic build only: read (and optionally clear) K2's lane statistics (vpt_implicit_kernel.hip.h)
-int vpt_debug_k2_stats(unsigned long long* out16, int reset) {
-  if (out16) HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_k2_stats), sizeof(unsigned long long) * 16));
+int vpt_debug_k2_stats(unsigned long long* out24, int reset) {
+  if (out24) HIP_TRY(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_k2_stats), sizeof(unsigned long long) * 24));
   if (reset) {
-    unsigned long long zero[16] = {};
+    unsigned long long zero[24] = {};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_k2_stats), zero, sizeof(zero)));
   }
   return VPT_OK;

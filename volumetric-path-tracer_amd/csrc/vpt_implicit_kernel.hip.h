@@ -39,6 +39,14 @@
 // The light rounds (21 % of the wave time at 14 of 64 lanes) disappear, but every scene step then carries the light lanes'
 // bookkeeping (exit tests, receding test, the second set of march registers): 301 against 297 Msamples/s on 06_gridsdf_full, 118
 // against 124 on 07_sdfunction_synth (profiles/r03_k2_experiments.txt).
+// Round 4: GROUP FORM of the scene march (kept).  A quarter of the scene-march rounds hold <= 16 marching rays and a fifth <= 8
+// (profiles/r04_k2_lane_histogram.txt): the tail of a tile, when most of its pixels are finished or wait for the shading block.  Such a
+// round runs with FOUR lanes per ray - ray k of the set on lanes 4k .. 4k+3, whoever owns them - each lane evaluating the SDFs j, j + 4, ...
+// of the scene's list and the four partial minima meeting by DPP (eval_sdf_scene_group: first minimum wins, as in the reference); the ray's
+// state travels by ds_bpermute once per round of VPT_K2_STEPS steps.  06_gridsdf_full 363 -> 388 Msamples/s, 07_sdfunction_synth (ten analytic
+// SDFs) 141 -> 189; bit-identical (KAT tables, every whole-path case).  Re-measured with it: 4 waves per SIMD 356 / 180 (5 stay), SHADE_AT 16 /
+// 28: 381 / 386, LIGHT_AT 2 / 8: 379 / 393 (but 169 on 07), STEPS 4 / 16: 372 / 395 (187 on 07): the round-3 settings stay.  Not kept: the
+// radiance sum and the pixel coordinates parked in LDS as in K1 (scratch 260 -> 248 B per lane, 381 against 386 Msamples/s).
 #pragma once
 #include "vpt_mesh_kernel.hip.h"
 
@@ -63,15 +71,19 @@
 #ifndef VPT_K2_LIGHT_EXIT
 #define VPT_K2_LIGHT_EXIT 0     // leave a light round as soon as none of its marches is alive
 #endif
+#ifndef VPT_K2_GROUP_MAX
+#define VPT_K2_GROUP_MAX 16  // scene-march rounds with at most this many marching rays run four lanes per ray (0: never)
+#endif
 #ifndef VPT_K2_STEPS
 #define VPT_K2_STEPS 8       // march steps between two looks at the wave's state (2: -5 %, 4: -1.5 %, 8: best)
 #endif
 
 // Diagnostic build (-DVPT_K2_STATS): where the lanes of a wave are, trip by trip (profiles/tools/k2_stats.py).  Never in the product build.
 #ifdef VPT_K2_STATS
-__device__ unsigned long long g_k2_stats[16];
+__device__ unsigned long long g_k2_stats[24];
 enum { KS_TRIPS, KS_SCENE_ROUNDS, KS_SCENE_LANES, KS_LIGHT_ROUNDS, KS_LIGHT_LANES, KS_SHADE_ROUNDS, KS_SHADE_LANES, KS_DONE_LANES,
-  KS_WAIT_LANES_AT_MARCH, KS_LIGHT_LANES_AT_SCENE, KS_SCENE_LANES_AT_SHADE, KS_CLK_SCENE, KS_CLK_LIGHT, KS_CLK_SHADE, KS_CLK_TOTAL, KS_COUNT };
+  KS_WAIT_LANES_AT_MARCH, KS_LIGHT_LANES_AT_SCENE, KS_SCENE_LANES_AT_SHADE, KS_CLK_SCENE, KS_CLK_LIGHT, KS_CLK_SHADE, KS_CLK_TOTAL,
+  KS_SCENE_LE8, KS_SCENE_LE16, KS_SCENE_LE32, KS_SCENE_LANES_LE16, KS_SCENE_LANES_LE32, KS_COUNT };
 #define K2_STAT(k, v) stats[k] += (unsigned long long)(v)
 // shader-clock stamp that the scheduler cannot move (diagnostic build only)
 #define K2_CLOCK(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) : : "memory")
@@ -84,11 +96,38 @@ enum { KS_TRIPS, KS_SCENE_ROUNDS, KS_SCENE_LANES, KS_LIGHT_ROUNDS, KS_LIGHT_LANE
 
 enum { M_NEW = 0, M_SCENE = 1, M_HIT = 2, M_MISS = 3, M_LIGHT = 4, M_LIGHTS = 5, M_DONE = 6 };
 
-// one step of spheretrace(scene, ray, maxiter) (yocto_pathtrace.cpp:289-307); returns the lane's next mode
-VPT_DEV int scene_march_step(const DScene& sc, const sdf_recs& recs, f3 ro, f3 rd, int maxiter, float& t, int& it, int& hit_instance, int& hit_sdf) {
+// eval_sdf_scene (yocto_sdfs.cpp:7-26) by the four lanes of a group for ONE point: lane j evaluates the SDFs j, j + 4, ... of the list
+// [voxel-grid instances][analytic SDFs] - the order the reference walks - and the four partial minima meet by DPP.  The reference keeps
+// the FIRST minimum (`d < result`), so do the lanes (strict <, ascending) and the reduction (smaller value, on a tie the smaller index):
+// the same (value, index) as the sequential loop, and every SDF value is computed by the same function from the same point.  All four
+// lanes of a group must be active and hold the same p and t.
+VPT_DEV sdf_hit eval_sdf_scene_group(const DScene& sc, const sdf_recs& recs, f3 p, float t, int j) {
+  const int G = sc.num_vol_instances, S = G + sc.num_sdfs;
+  float best = VPT_FLT_MAX;
+  int   bc   = 0x7fffffff;
+  for (int c = j; c < S; c += 4) {
+    float d = c < G ? sdf_grid_world(sc, recs, c, p, t) : sdf_fn_world(recs, c - G, p);
+    if (d < best) best = d, bc = c;
+  }
+  float ob = __int_as_float(quad_xor1(__float_as_int(best)));
+  int   oc = quad_xor1(bc);
+  bool  take = ob < best || (ob == best && oc < bc);
+  best = take ? ob : best, bc = take ? oc : bc;
+  ob = __int_as_float(quad_xor2(__float_as_int(best))), oc = quad_xor2(bc);
+  take = ob < best || (ob == best && oc < bc);
+  best = take ? ob : best, bc = take ? oc : bc;
+  sdf_hit res = {best, bc < G ? bc : -1, (bc >= G && bc < S) ? bc - G : -1};
+  return res;
+}
+
+// one step of spheretrace(scene, ray, maxiter) (yocto_pathtrace.cpp:289-307); returns the lane's next mode.  GROUP: the step of a ray that
+// four lanes hold together (group_lane = the lane's place in its group): the scene SDF is evaluated by eval_sdf_scene_group, the rest by
+// every lane alike
+template <bool GROUP = false>
+VPT_DEV int scene_march_step(const DScene& sc, const sdf_recs& recs, f3 ro, f3 rd, int maxiter, float& t, int& it, int& hit_instance, int& hit_sdf, int group_lane = 0) {
   if (!(it < maxiter && t < VPT_FLT_MAX)) return M_MISS;
   f3      p   = ro + rd * t;
-  sdf_hit res = eval_sdf_scene(sc, recs, p, t);
+  sdf_hit res = GROUP ? eval_sdf_scene_group(sc, recs, p, t, group_lane) : eval_sdf_scene(sc, recs, p, t);
   if (__builtin_fabsf(res.result) < (VPT_FLT_EPS * t)) {   // |x| < y and the ternary abs(x) < y agree for every x (they differ in the sign of a zero only)
     hit_instance = res.instance, hit_sdf = res.sdf;
     return M_HIT;
@@ -228,9 +267,40 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
       // ---- march steps ------------------------------------------------------------------------------
       K2_STAT(KS_WAIT_LANES_AT_MARCH, __popcll(waiting));
       K2_CLOCK(c0);
-      if (__builtin_amdgcn_ballot_w64(mode == M_SCENE) != 0) {
+      const unsigned long long ms = __builtin_amdgcn_ballot_w64(mode == M_SCENE);
+      if (VPT_K2_GROUP_MAX > 0 && ms != 0 && __popcll(ms) <= VPT_K2_GROUP_MAX) {
+        // A small set of marching rays (a quarter of the scene rounds hold <= 16, a fifth <= 8: profiles/r04_k2_lane_histogram.txt): ray k of the
+        // set on lanes 4k .. 4k+3 - whoever owns them: lanes whose pixel is finished, lanes that wait for the shading block - each lane
+        // evaluating a quarter of the scene's SDFs per step (eval_sdf_scene_group); the ray's t sequence is the reference's, step for step
+        K2_STAT(KS_SCENE_ROUNDS, 1);
+        K2_STAT(KS_SCENE_LANES, __popcll(ms));
+        K2_STAT(KS_SCENE_LE16, 1);
+        const int  lane = threadIdx.x, gj = lane & 3;
+        const bool mine = (ms >> lane) & 1;
+        const int  rank = lanes_below(ms), nrays = __popcll(ms);
+        int        gowner = quad_lane0(__builtin_amdgcn_ds_permute(mine ? rank << 4 : 4, lane));   // ray k's owner posts its lane number to lane 4k
+        const bool gact = (lane >> 2) < nrays;
+        if (!gact) gowner = lane;
+        const f3 gro = pull(gowner, ro), grd = pull(gowner, rd);
+        float    gt  = pull(gowner, t);
+        int      git = pull(gowner, it), gmode = gact ? M_SCENE : M_DONE, ghi = -1, ghs = -1;
+        for (int k = 0; k < VPT_K2_STEPS && __builtin_amdgcn_ballot_w64(gmode == M_SCENE) != 0; k++)
+          if (gmode == M_SCENE) gmode = scene_march_step<true>(sc, recs, gro, grd, maxiter, gt, git, ghi, ghs, gj);
+        const int   src = mine ? rank << 2 : 0;   // the owner of ray k reads lane 4k
+        const int   nmode = pull(src, gmode), nit = pull(src, git), nhi = pull(src, ghi), nhs = pull(src, ghs);
+        const float nt = pull(src, gt);
+        if (mine) {
+          mode = nmode, t = nt, it = nit;
+          if (nmode == M_HIT) hit_instance = nhi, hit_sdf = nhs;
+        }
+      } else if (ms != 0) {
         K2_STAT(KS_SCENE_ROUNDS, 1);
         K2_STAT(KS_SCENE_LANES, __popcll(__builtin_amdgcn_ballot_w64(mode == M_SCENE)));
+        K2_STAT(KS_SCENE_LE8, __popcll(__builtin_amdgcn_ballot_w64(mode == M_SCENE)) <= 8);
+        K2_STAT(KS_SCENE_LE16, __popcll(__builtin_amdgcn_ballot_w64(mode == M_SCENE)) <= 16);
+        K2_STAT(KS_SCENE_LE32, __popcll(__builtin_amdgcn_ballot_w64(mode == M_SCENE)) <= 32);
+        K2_STAT(KS_SCENE_LANES_LE16, __popcll(__builtin_amdgcn_ballot_w64(mode == M_SCENE)) <= 16 ? __popcll(__builtin_amdgcn_ballot_w64(mode == M_SCENE)) : 0);
+        K2_STAT(KS_SCENE_LANES_LE32, __popcll(__builtin_amdgcn_ballot_w64(mode == M_SCENE)) <= 32 ? __popcll(__builtin_amdgcn_ballot_w64(mode == M_SCENE)) : 0);
         K2_STAT(KS_LIGHT_LANES_AT_SCENE, __popcll(__builtin_amdgcn_ballot_w64(mode == M_LIGHT)));
         for (int k = 0; k < VPT_K2_STEPS; k++)
           if (mode == M_SCENE) mode = scene_march_step(sc, recs, ro, rd, maxiter, t, it, hit_instance, hit_sdf);

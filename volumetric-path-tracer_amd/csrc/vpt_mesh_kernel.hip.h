@@ -545,7 +545,16 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
     const unsigned long long ma = __builtin_amdgcn_ballot_w64(!done && cur >= 0);
     if (ma != 0) {
       if (VPT_COOP_MAX > 0 && whole_wave && __popcll(ma) <= VPT_COOP_MAX) group_nodes(ma);
+#ifdef VPT_DENSE_LOOP
+      else {   // a large set: own steps until it has shrunk to a small one
+        const int few = whole_wave ? VPT_COOP_MAX : 0;
+        do {
+          if (!done && cur >= 0) own_node_step();
+        } while (__popcll(__builtin_amdgcn_ballot_w64(!done && cur >= 0)) > few);
+      }
+#else
       else if (!done && cur >= 0) own_node_step();
+#endif
       VPT_T1(TM_NODES);
       continue;
     }

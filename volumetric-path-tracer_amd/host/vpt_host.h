@@ -191,9 +191,16 @@ struct subdiv_level {
 };
 void catmullclark_topology(const vector<vec4i>& quads, int num_vertices, bool lock_boundary, subdiv_level& level);
 void subdivide_vertices(const subdiv_level& level, int dim, const vector<float>& verts, vector<float>& out);
-// Extension: the same with the per-level vertex arithmetic (edge and face points, the averaging pass in face order,
-// the correction pass) on GPU `device` through vpt_subdivide_vertices; topology stays on the host.  Same bits.
+// Extension: the same with every float stage on GPU `device` - the per-level vertex arithmetic (edge and face points, the
+// averaging pass in face order, the correction pass: vpt_subdivide_vertices), the smooth normals before and after the
+// displacement (vpt_vertex_normals) and the displacement itself (vpt_displace_vertices); the integer work - topology,
+// split_facevarying, quads_to_triangles - stays on the host.  Same bits.
 void             tesselate_surfaces_device(scene_data& scene, int device = 0);
+// Single stages of tesselate_surface (device < 0: the host loops; else GPU `device`: vpt_vertex_normals / vpt_displace_vertices):
+// quads_normals / triangles_normals (yocto_shape.cpp:1478-1512; corners = 4 / 3) and the displacement step (cpp:1259-1265).
+vector<vec3f>    vertex_normals(const vector<vec3f>& positions, const int* faces, int num_faces, int corners, int device = -1);
+vector<vec3f>    displace_vertices(const texture_data& texture, float displacement, const vector<vec3f>& positions, const vector<vec3f>& normals,
+       const vector<vec2f>& texcoords, int device = -1);
 // Progressively computes an image: ONE sample per pixel per call, on the GPU (vpt_render).
 // Throws std::runtime_error("sampler unknown") for a bad shader (reference cpp:947-950) and
 // std::runtime_error with vpt_last_error() if the HIP path is unavailable — there is no CPU

@@ -78,6 +78,40 @@ int vpth_catmullclark(const int32_t* quads, int nquads, const float* verts, int 
     return set_error(err, errlen, e.what()), -1;
   }
 }
+// quads_normals (corners = 4) / triangles_normals (3) over float3 positions: host loops (device < 0) or vpt_vertex_normals on that GPU
+int vpth_vertex_normals(const float* positions, int nverts, const int32_t* faces, int nfaces, int corners, int device, float* normals, char* err, int errlen) {
+  try {
+    if (corners != 3 && corners != 4) throw std::invalid_argument{"corners must be 3 or 4"};
+    for (long long i = 0; i < (long long)nfaces * corners; i++)
+      if (faces[i] < 0 || faces[i] >= nverts) throw std::invalid_argument{"face index out of range"};
+    auto pos = vector<vec3f>((size_t)nverts);
+    memcpy((void*)pos.data(), positions, (size_t)nverts * 12);
+    auto out = vertex_normals(pos, faces, nfaces, corners, device);
+    memcpy(normals, out.data(), (size_t)nverts * 12);
+    return 0;
+  } catch (const std::exception& e) {
+    return set_error(err, errlen, e.what()), -1;
+  }
+}
+// the displacement step of tesselate_surface over float3 positions / normals and float2 texcoords; texels: uchar4 or float4 by is_float
+int vpth_displace_vertices(const void* texels, int width, int height, int is_float, int linear, float displacement, const float* positions,
+    const float* normals, const float* texcoords, int nverts, int device, float* out_positions, char* err, int errlen) {
+  try {
+    auto tex = texture_data{};
+    tex.width = width, tex.height = height, tex.linear = linear != 0;
+    if (is_float) tex.pixelsf.assign((const vec4f*)texels, (const vec4f*)texels + (size_t)width * height);
+    else tex.pixelsb.assign((const vec4b*)texels, (const vec4b*)texels + (size_t)width * height);
+    auto pos = vector<vec3f>((size_t)nverts), nrm = vector<vec3f>((size_t)nverts);
+    auto uv  = vector<vec2f>((size_t)nverts);
+    memcpy((void*)pos.data(), positions, (size_t)nverts * 12), memcpy((void*)nrm.data(), normals, (size_t)nverts * 12);
+    memcpy((void*)uv.data(), texcoords, (size_t)nverts * 8);
+    auto out = displace_vertices(tex, displacement, pos, nrm, uv, device);
+    memcpy(out_positions, out.data(), (size_t)nverts * 12);
+    return 0;
+  } catch (const std::exception& e) {
+    return set_error(err, errlen, e.what()), -1;
+  }
+}
 // rebuild the scene's BVHs on GPU `device` (make_bvh_device) and flatten again; 0 on success
 int vpth_scene_rebuild_bvh_device(void* hh, int device, char* err, int errlen) {
   try {

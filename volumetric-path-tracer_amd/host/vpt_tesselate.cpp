@@ -18,6 +18,7 @@
 // hash (yocto_shape.h:376-384) filled in the same order, so with the same libstdc++ it iterates identically.
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <stdexcept>
 #include <unordered_map>
 
@@ -341,9 +342,25 @@ void check_cage(const subdiv_data& subdiv) {   // the reference trusts its files
     throw std::invalid_argument{"subdiv cage with indices out of range"};
 }
 
-// tesselate_surface, yocto_pathtrace.cpp:1228-1273; `level` runs one Catmull-Clark level on (quads, flat vertex floats)
-template <typename Level>
-void tesselate_surface(shape_data& shape, const subdiv_data& subdiv_, const scene_data& scene, Level level) {
+// where the float work of tesselate_surface runs: the host loops above, or the device kernels of csrc/vpt_subdiv.hip
+struct tess_ops {
+  std::function<void(vector<vec4i>&, vector<float>&, int, bool)>                           level;             // one Catmull-Clark level on (quads, flat vertex floats)
+  std::function<vector<vec3f>(const vector<vec4i>&, const vector<vec3f>&)>                 normals_of_quads;
+  std::function<vector<vec3f>(const vector<vec3i>&, const vector<vec3f>&)>                 normals_of_triangles;
+  std::function<void(const texture_data&, float, const shape_data&, vector<vec3f>&)>       displace;          // positions out
+};
+void displace_host(const texture_data& displacement_tex, float displacement, const shape_data& shape, vector<vec3f>& positions) {
+  positions.resize(shape.positions.size());
+  for (size_t idx = 0; idx < shape.positions.size(); idx++) {
+    auto texel = eval_texture_linear(displacement_tex, shape.texcoords[idx]);
+    auto disp  = (texel.x + texel.y + texel.z) / 3;   // mean(xyz(.))
+    if (!displacement_tex.pixelsb.empty()) disp -= 0.5f;
+    positions[idx] = shape.positions[idx] + shape.normals[idx] * displacement * disp;
+  }
+}
+// tesselate_surface, yocto_pathtrace.cpp:1228-1273
+void tesselate_surface(shape_data& shape, const subdiv_data& subdiv_, const scene_data& scene, const tess_ops& ops) {
+  auto& level = ops.level;
   auto subdiv = subdiv_;
   check_cage(subdiv);
   if (subdiv.subdivisions != 0) {
@@ -358,7 +375,7 @@ void tesselate_surface(shape_data& shape, const subdiv_data& subdiv_, const scen
     subdiv.texcoords.resize(flat.size() / 2);
     memcpy((void*)subdiv.texcoords.data(), flat.data(), flat.size() * 4);
     if (subdiv.smooth) {
-      subdiv.normals   = quads_normals(subdiv.quadspos, subdiv.positions);
+      subdiv.normals   = ops.normals_of_quads(subdiv.quadspos, subdiv.positions);
       subdiv.quadsnorm = subdiv.quadspos;
     } else {
       subdiv.normals   = {};
@@ -376,24 +393,51 @@ void tesselate_surface(shape_data& shape, const subdiv_data& subdiv_, const scen
   shape.points = {};
   if (subdiv.displacement != 0 && subdiv.displacement_tex >= 0 && !shape.triangles.empty()) {
     if (shape.texcoords.size() != shape.positions.size()) throw std::invalid_argument{"displaced subdiv without texture coordinates"};
-    if (shape.normals.empty()) shape.normals = triangles_normals(shape.triangles, shape.positions);
+    if (shape.normals.empty()) shape.normals = ops.normals_of_triangles(shape.triangles, shape.positions);
     auto& displacement_tex = scene.textures.at((size_t)subdiv.displacement_tex);
-    for (size_t idx = 0; idx < shape.positions.size(); idx++) {
-      auto texel = eval_texture_linear(displacement_tex, shape.texcoords[idx]);
-      auto disp  = (texel.x + texel.y + texel.z) / 3;   // mean(xyz(.))
-      if (!displacement_tex.pixelsb.empty()) disp -= 0.5f;
-      shape.positions[idx] = shape.positions[idx] + shape.normals[idx] * subdiv.displacement * disp;
-    }
-    if (subdiv.smooth) shape.normals = triangles_normals(shape.triangles, shape.positions);
+    auto  displaced = vector<vec3f>{};
+    ops.displace(displacement_tex, subdiv.displacement, shape, displaced);
+    shape.positions = std::move(displaced);
+    if (subdiv.smooth) shape.normals = ops.normals_of_triangles(shape.triangles, shape.positions);
     else shape.normals = {};
   }
 }
 }  // namespace
 
 void tesselate_surfaces(scene_data& scene) {
-  for (auto& subdiv : scene.subdivs)
-    tesselate_surface(scene.shapes.at((size_t)subdiv.shape), subdiv, scene,
-        [](vector<vec4i>& quads, vector<float>& verts, int dim, bool lock) { tesselate_catmullclark(quads, verts, dim, lock); });
+  auto ops = tess_ops{[](vector<vec4i>& quads, vector<float>& verts, int dim, bool lock) { tesselate_catmullclark(quads, verts, dim, lock); },
+      quads_normals, triangles_normals, displace_host};
+  for (auto& subdiv : scene.subdivs) tesselate_surface(scene.shapes.at((size_t)subdiv.shape), subdiv, scene, ops);
+}
+
+// the same stages one at a time (tests, profiles/tools/tesselation_timing.py): device < 0 host, else that GPU
+vector<vec3f> vertex_normals(const vector<vec3f>& positions, const int* faces, int num_faces, int corners, int device) {
+  if (device < 0) {
+    if (corners == 4) return quads_normals(vector<vec4i>((const vec4i*)faces, (const vec4i*)faces + num_faces), positions);
+    return triangles_normals(vector<vec3i>((const vec3i*)faces, (const vec3i*)faces + num_faces), positions);
+  }
+  auto normals = vector<vec3f>(positions.size());
+  if (vpt_vertex_normals(device, (int)positions.size(), &positions.data()->x, num_faces, corners, faces, &normals.data()->x) != VPT_OK)
+    throw std::runtime_error{string{"vpt_vertex_normals: "} + vpt_last_error()};
+  return normals;
+}
+static void displace_device(int device, const texture_data& tex, float displacement, const shape_data& shape, vector<vec3f>& positions) {
+  auto desc = vpt_texture{tex.width, tex.height, tex.linear ? 1 : 0, tex.pixelsf.empty() ? 0 : 1, 0};
+  auto texels = tex.pixelsf.empty() ? (const void*)tex.pixelsb.data() : (const void*)tex.pixelsf.data();
+  positions.resize(shape.positions.size());
+  if (vpt_displace_vertices(device, &desc, texels, displacement, (int)shape.positions.size(), &shape.positions.data()->x, &shape.normals.data()->x,
+          &shape.texcoords.data()->x, &positions.data()->x) != VPT_OK)
+    throw std::runtime_error{string{"vpt_displace_vertices: "} + vpt_last_error()};
+}
+vector<vec3f> displace_vertices(const texture_data& tex, float displacement, const vector<vec3f>& positions, const vector<vec3f>& normals,
+    const vector<vec2f>& texcoords, int device) {
+  if (normals.size() != positions.size() || texcoords.size() != positions.size()) throw std::invalid_argument{"displacement needs a normal and a texture coordinate per vertex"};
+  auto shape = shape_data{};
+  shape.positions = positions, shape.normals = normals, shape.texcoords = texcoords;
+  auto out = vector<vec3f>{};
+  if (device < 0) displace_host(tex, displacement, shape, out);
+  else displace_device(device, tex, displacement, shape, out);
+  return out;
 }
 
 void tesselate_surfaces_device(scene_data& scene, int device) {
@@ -408,7 +452,11 @@ void tesselate_surfaces_device(scene_data& scene, int device) {
     verts = std::move(next);
     quads = std::move(L.tquads);
   };
-  for (auto& subdiv : scene.subdivs) tesselate_surface(scene.shapes.at((size_t)subdiv.shape), subdiv, scene, level);
+  auto ops = tess_ops{level,
+      [device](const vector<vec4i>& quads, const vector<vec3f>& positions) { return vertex_normals(positions, &quads.data()->x, (int)quads.size(), 4, device); },
+      [device](const vector<vec3i>& triangles, const vector<vec3f>& positions) { return vertex_normals(positions, &triangles.data()->x, (int)triangles.size(), 3, device); },
+      [device](const texture_data& tex, float displacement, const shape_data& shape, vector<vec3f>& positions) { displace_device(device, tex, displacement, shape, positions); }};
+  for (auto& subdiv : scene.subdivs) tesselate_surface(scene.shapes.at((size_t)subdiv.shape), subdiv, scene, ops);
 }
 
 }  // namespace vpt

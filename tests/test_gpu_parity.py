@@ -415,3 +415,50 @@ def test_intersect_is_bit_identical_on_edge_case_rays(vpt, oracle, scene_file, l
                 assert (ids[:, 0] >= 0).mean() > 0.05   # the batch does hit things
             assert np.array_equal(ids, rids), (name, instance, np.nonzero((ids != rids).any(axis=1))[0][:10])
             assert np.array_equal(uvt.view(np.uint32), ruvt.view(np.uint32)), (name, instance, np.nonzero((uvt.view(np.uint32) != ruvt.view(np.uint32)).any(axis=1))[0][:10])
+
+
+def test_intersect_follows_the_reference_through_nan_hits(vpt, oracle, tmp_path):
+    """A triangle of denormal size met exactly at its first corner gives det != 0 with 1 / det = inf and u = v = t = 0 * inf = NaN, which
+    intersect_triangle's comparisons all let through (yocto_geometry.h:786-819): the reference records a hit with a NaN distance, and from
+    then on ray.tmax = NaN accepts every later primitive of the leaf and fails every later box test.  The group form of the leaf phase tests a
+    leaf's primitives in parallel, which is the sequential loop only while no NaN is in play: it must notice and hand the leaf back.  Rays
+    from the corner (NaN hits, dense and sparse waves) and rays that pass near it must match the oracle: ids exactly, floats bit for bit or NaN for NaN."""
+    tiny = 1e-20
+    obj = ["v -1 -1 -1", "v 1 -1 -1", "v 1 1 -1", "v -1 1 -1",                   # a wall behind
+           "v 0 0 0", f"v {tiny} 0 0", f"v 0 {tiny} 0",                          # the degenerate triangle at the origin
+           "v -1 -1 1", "v 1 -1 1", "v 1 1 1", "v -1 1 1"]                       # a wall in front
+    faces = ["f 1 2 3", "f 1 3 4", "f 5 6 7", "f 8 9 10", "f 8 10 11"]
+    rng = np.random.default_rng(3)
+    for k in range(40):                                                           # clutter, so that the BVH has several leaves and levels
+        c = rng.uniform(-0.9, 0.9, 3)
+        n = len(obj)
+        obj += [f"v {c[0]} {c[1]} {c[2]}", f"v {c[0] + 0.1} {c[1]} {c[2]}", f"v {c[0]} {c[1] + 0.1} {c[2]}"]
+        faces.append(f"f {n + 1} {n + 2} {n + 3}")
+    (tmp_path / "a.obj").write_text("\n".join(obj + faces) + "\n")
+    desc = {"asset": {"version": "4.2"}, "cameras": [{"name": "c", "aspect": 1.0}], "materials": [{"name": "m", "type": "matte", "color": [0.5, 0.5, 0.5]}],
+            "shapes": [{"name": "s", "uri": "a.obj"}], "instances": [{"name": "i", "shape": 0, "material": 0}]}
+    import json
+    (tmp_path / "scene.json").write_text(json.dumps(desc))
+    scene = vpt.HostScene(str(tmp_path / "scene.json"))
+    dev = vpt.DeviceScene(scene, 0)
+    n = 64 * 40
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 6), np.float32)
+    rays[:, 3:] = d                                                                # all from the corner itself: tvec == 0
+    near = rays.copy()
+    near[:, :3] = rng.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32)           # ordinary rays through the same tree
+    far = np.float32([1e3, 1e3, 1e3, 0.57735027, 0.57735027, 0.57735027])
+    sparse = rays.copy()
+    sparse[(np.arange(n) * 7 + 3) % 64 >= 5] = far                                 # five corner rays per wave: group forms from the first node on
+    mixed = np.where((np.arange(n) % 3 == 0)[:, None], rays, near)
+    saw_nan = 0
+    for name, batch in (("corner", rays), ("near", near), ("sparse", sparse), ("mixed", mixed)):
+        for instance in (-1, 0):
+            ids, uvt = dev.intersect(batch, instance)
+            rids, ruvt = oracle.oracle_intersect(scene, batch, instance)
+            assert np.array_equal(ids, rids), (name, instance, np.nonzero((ids != rids).any(axis=1))[0][:10])
+            same = (uvt.view(np.uint32) == ruvt.view(np.uint32)) | (np.isnan(uvt) & np.isnan(ruvt))
+            assert same.all(), (name, instance, np.nonzero(~same.all(axis=1))[0][:10])
+            saw_nan += int(np.isnan(ruvt[:, 2]).sum())
+    assert saw_nan > 100                                                           # the case this test is about did occur

@@ -1030,7 +1030,8 @@ static void schedule_key(const launch_ctx& L, long long key[10]) {
 // camera from the per-tile costs of an unsplit launch, when the launch is short of waves: the frame is shared among ranks
 // or holds fewer than three tiles per wave slot (1280x533 on one MI355X has 3.5 and never gains).  Pixels keep their own RNG streams and accumulators, so the result does
 // not depend on it.
-static double split_gain[7] = {1.0, 0.81, 0.62, 0.45, 0.35, 0.27, 0.20};   // duration of a 64 >> k lane wave of a costly tile / its full wave
+static double split_gain[7] = {1.0, 0.75, 0.57, 0.44, 0.34, 0.27, 0.20};   // duration of a 64 >> k lane wave of a costly tile / its full wave (round 4's
+                                                                           // kernel, whose partly filled waves use their empty lanes as helpers: 0.753 / 0.566 / 0.436 / 0.343 measured, was 0.81 / 0.62 / 0.45 / 0.35)
 static double split_load0 = 0.46, split_margin = 0.98;   // load_factor's intercept; a split has to beat the unsplit launch by this factor
 static void split_tuning() {   // VPT_SPLIT_TUNE="g1,g2,g3,g4,g5,g6,load0,margin" (calibration runs only)
   static bool once = [] {

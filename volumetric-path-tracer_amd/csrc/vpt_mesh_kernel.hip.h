@@ -208,7 +208,7 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
   // (a lane without a ray holds whatever its last ray left in wo / wd: it must not steer the wave-wide choices of the reciprocal and slab forms)
   const f3   winv = rcp3_exact(active ? wd : mk3(1, 1, 1));
   const int  wsgn = sign_bits(winv);
-  const bool wslow = active && nan_prone(wd, winv);
+  bool       wslow = active && nan_prone(wd, winv);
   f3    co = wo, cd = wd, cinv = winv;
   int   csgn = wsgn;
   bool  slow = wslow;
@@ -248,7 +248,7 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
       if (general) {
         frame inv = unpack_frame(e[0], e[1], e2);
         co = transform_point(inv, wo), cd = transform_vector(inv, wd);
-        cinv = rcp3_exact(cd), slow = nan_prone(cd, cinv);
+        cinv = rcp3_exact(cd), slow = nan_prone(cd, cinv) || tmax != tmax;   // (a NaN tmax: own_leaf)
       } else {
         co = mk3(wo.x + e2.y, wo.y + e2.z, wo.z + e2.w);
       }
@@ -398,6 +398,10 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
       if (intersect_quad(co, cd, tmin, tmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), r.uv, r.distance))
         r.hit = true, r.element = __float_as_int(r0.w), r.instance = cur_inst, tmax = r.distance, r.prim = leafb + start + k;
     }
+    // A hit with a NaN distance (a triangle of denormal size met exactly at a corner: 0 * inf) leaves tmax = NaN, and the reference's
+    // fmin(far, tmax) = (far < tmax) ? far : tmax then fails every later box test.  The hardware min / max of the fast box forms drop a
+    // NaN operand instead, so such a ray walks on in the reference's NaN-asymmetric form (tests/test_gpu_parity.py: degenerate triangles)
+    if (tmax != tmax) slow = true, wslow = true;
     cur = pop_valid();
   };
 

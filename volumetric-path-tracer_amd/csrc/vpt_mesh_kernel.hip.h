@@ -195,6 +195,12 @@ VPT_DEV bool slab_pass_signed(float nx, float ny, float nz, float fx, float fy, 
 #ifndef VPT_COOP_MAX
 #define VPT_COOP_MAX 16    // a phase with at most this many rays runs in its group form (four lanes per ray); 0: own forms only
 #endif
+#ifndef VPT_COOP_NODES
+#define VPT_COOP_NODES VPT_COOP_MAX   // (experiments: the group form of one phase only)
+#endif
+#ifndef VPT_COOP_LEAVES
+#define VPT_COOP_LEAVES VPT_COOP_MAX
+#endif
 #ifdef VPT_TRAVERSE_GUARD
 __device__ unsigned g_vpt_guard_trips;   // diagnostic build: queries that were cut short after VPT_TRAVERSE_GUARD loop rounds (must stay 0)
 #endif
@@ -548,10 +554,10 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
     VPT_T0(TM_NODES);
     const unsigned long long ma = __builtin_amdgcn_ballot_w64(!done && cur >= 0);
     if (ma != 0) {
-      if (VPT_COOP_MAX > 0 && whole_wave && __popcll(ma) <= VPT_COOP_MAX) group_nodes(ma);
+      if (VPT_COOP_NODES > 0 && whole_wave && __popcll(ma) <= VPT_COOP_NODES) group_nodes(ma);
 #ifdef VPT_DENSE_LOOP
       else {   // a large set: own steps until it has shrunk to a small one
-        const int few = whole_wave ? VPT_COOP_MAX : 0;
+        const int few = whole_wave ? VPT_COOP_NODES : 0;
         do {
           if (!done && cur >= 0) own_node_step();
         } while (__popcll(__builtin_amdgcn_ballot_w64(!done && cur >= 0)) > few);
@@ -569,7 +575,7 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
       const bool at_leaf = !done && cur != VPT_NONE && shape_base >= 0;   // (cur < 0 for every lane here)
       const unsigned long long mb = __builtin_amdgcn_ballot_w64(at_leaf);
       bool own = at_leaf;
-      if (VPT_COOP_MAX > 0 && whole_wave && mb != 0 && __popcll(mb) <= VPT_COOP_MAX) {
+      if (VPT_COOP_LEAVES > 0 && whole_wave && mb != 0 && __popcll(mb) <= VPT_COOP_LEAVES) {
         own = group_leaves(mb);
         if (at_leaf && !own) cur = pop_valid();
       }

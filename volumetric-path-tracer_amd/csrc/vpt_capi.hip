@@ -1557,6 +1557,14 @@ int vpt_debug_k2_stats(unsigned long long* out24, int reset) {
 
 #ifdef VPT_COUNTERS
 // diagnostic build only: read (and optionally clear) the section counters of vpt_mesh_kernel.hip.h
+int vpt_debug_hist(unsigned long long* out24, int reset) {
+  if (out24) HIP_TRY(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_vpt_hist), sizeof(unsigned long long) * 24));
+  if (reset) {
+    unsigned long long zero[24] = {};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_vpt_hist), zero, sizeof(zero)));
+  }
+  return VPT_OK;
+}
 int vpt_debug_counts(unsigned long long* out64, int reset) {
   if (out64) HIP_TRY(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_vpt_cnt), sizeof(unsigned long long) * 64));
   if (reset) {

@@ -437,6 +437,7 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
     const STK  gstk = stk.of_lane(owner);
     while (__builtin_amdgcn_ballot_w64(gcur >= 0) != 0) {
       VPT_CNT_MASK(CNT_GNODE, __builtin_amdgcn_ballot_w64(gcur >= 0));
+      VPT_HIST(__popcll(__builtin_amdgcn_ballot_w64(gcur >= 0)) >> 2);
 #ifdef VPT_TRAVERSE_GUARD
       if (++guard > VPT_TRAVERSE_GUARD) gcur = VPT_NONE;   // (the outer loop reports it)
 #endif

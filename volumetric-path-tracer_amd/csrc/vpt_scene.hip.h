@@ -33,6 +33,13 @@ VPT_DEV void vpt_cnt_mask(int k, unsigned long long part) {
   }
 }
 #define VPT_CNT_MASK(k, part) vpt_cnt_mask(k, part)
+// histogram of a small count (slots 0 .. 23 of g_vpt_hist): rays in a group-form node step
+__device__ unsigned long long g_vpt_hist[24];
+VPT_DEV void vpt_hist(int n) {
+  unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&g_vpt_hist[n < 23 ? n : 23], 1ull);
+}
+#define VPT_HIST(n) vpt_hist(n)
 // wave-level elapsed cycles per section: slot 32 + k of g_vpt_cnt (accumulated in LDS, flushed at kernel end)
 __shared__ unsigned long long s_vpt_time[16];
 VPT_DEV void vpt_time_add(int k, unsigned long long t0) {
@@ -45,11 +52,12 @@ VPT_DEV void vpt_time_add(int k, unsigned long long t0) {
 #else
 #define VPT_CNT(k)
 #define VPT_CNT_MASK(k, part)
+#define VPT_HIST(n)
 #define VPT_T0(k)
 #define VPT_T1(k)
 #endif
 enum { TM_NODES = 0, TM_PRIMS, TM_ENTER, TM_QUERY, TM_TRIP, TM_LIGHTS_PDF, TM_SAMPLE_LIGHTS, TM_SURFACE, TM_VOLUME, TM_GENERATE, TM_KERNEL, TM_CDF, TM_SCATTER_EVAL, TM_MEDIUM, TM_SURF_GEOM, TM_SURF_DELTA };
-enum { CNT_NODE = 0, CNT_PRIM, CNT_ENTER, CNT_OUTER, CNT_TRIP, CNT_POP, CNT_MISS, CNT_SURFACE, CNT_VOLUME, CNT_LIGHTS, CNT_GENERATE, CNT_LEAF, CNT_SESSION, CNT_GNODE, CNT_GLEAF };
+enum { CNT_NODE = 0, CNT_PRIM, CNT_ENTER, CNT_OUTER, CNT_TRIP, CNT_POP, CNT_MISS, CNT_SURFACE, CNT_VOLUME, CNT_LIGHTS, CNT_GENERATE, CNT_LEAF, CNT_SESSION, CNT_GNODE, CNT_GLEAF, CNT_WNODE };
 
 // ------------------------------------------------------------------------------------------------
 // per-lane traversal stack in LDS: entry e of lane t lives at lds[e * VPT_BLOCK + t], so the 64

@@ -262,7 +262,9 @@ class Bench:
             t = json.load(open(tfile))
             if t.get("bytes_per_sample"):
                 rec["traffic"] = round(t["bytes_per_sample"] * per_launch_samples)
-                rec["traffic_source"] = os.path.relpath(tfile, ROOT) + " (committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes, bytes per sample x this launch's samples)"
+                rec["traffic_source"] = (os.path.relpath(tfile, ROOT) + " (committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this kernel version, bytes per sample x this launch's "
+                                         "samples; the write half is almost entirely register-spill scratch cycling through L2, not data: "
+                                         f"{t.get('WRITE_SIZE_KB', 0) * 1024.0 / max(1, t.get('samples_per_launch', 1)):.0f} of {t['bytes_per_sample']:.0f} B per sample)")
         if implicit:
             # K2 is VALU-bound by a wide margin: its record is priced against the chip's VALU issue peak - wave-level VALU
             # instructions per sample from the committed SQ pass of this kernel x live samples/s / 1 228.8 G wave-instructions/s - and the

@@ -20,6 +20,8 @@
 //    fit); near / far planes chosen by the ray's sign and v_min3/v_max3 when no slab product can be NaN
 //    (identical results), the reference's NaN-asymmetric ternary form otherwise;
 //  * small scenes test the root boxes of all instances in lockstep at the start of a query (tmax = inf);
+//  * GROUP FORMS (round 4): every lane of the wave goes through every query - a lane without a ray as a helper - and a node or leaf
+//    phase that holds at most 16 rays runs on four lanes per ray (traverse(), below): the idle lanes of a query get work;
 //  * waves are launched longest first from the durations the previous launch recorded (sched_cfg).
 //
 // Exactness of the quad-node traversal.  The reference pops a node, tests its box against the current
@@ -556,16 +558,7 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
     const unsigned long long ma = __builtin_amdgcn_ballot_w64(!done && cur >= 0);
     if (ma != 0) {
       if (VPT_COOP_NODES > 0 && whole_wave && __popcll(ma) <= VPT_COOP_NODES) group_nodes(ma);
-#ifdef VPT_DENSE_LOOP
-      else {   // a large set: own steps until it has shrunk to a small one
-        const int few = whole_wave ? VPT_COOP_NODES : 0;
-        do {
-          if (!done && cur >= 0) own_node_step();
-        } while (__popcll(__builtin_amdgcn_ballot_w64(!done && cur >= 0)) > few);
-      }
-#else
       else if (!done && cur >= 0) own_node_step();
-#endif
       VPT_T1(TM_NODES);
       continue;
     }

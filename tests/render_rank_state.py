@@ -1,6 +1,6 @@
 """helper of tests/test_tile_splitting.py: render one virtual rank of an N-rank job on GPU 0 through the device-state API,
 several calls in a row, and save the rank's state (row-major, only its own pixels are touched) plus what the launches did.
-usage: render_rank_state.py <scene.json> <resolution> <nranks> <rank> <spp per call> <calls> <out.npz>"""
+usage: render_rank_state.py <scene.json> <resolution> <nranks> <rank> <spp per call> <calls> <out.npz> [shader [bounces]]"""
 import os
 import sys
 
@@ -16,7 +16,9 @@ vpt = vpt_loader.load()
 scene_file, res, nranks, rank, spp, calls, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
 scene = vpt.HostScene(scene_file)
 dev = vpt.DeviceScene(scene, 0)
-p = vpt.PathtraceParams(resolution=res, samples=1 << 20, shader="volpathtrace", bounces=64)
+shader = sys.argv[8] if len(sys.argv) > 8 else "volpathtrace"
+bounces = int(sys.argv[9]) if len(sys.argv) > 9 else 64
+p = vpt.PathtraceParams(resolution=res, samples=1 << 20, shader=shader, bounces=bounces)
 host = scene.make_state(p)
 lay = vpt.VptLayout(host.width, host.height, 8, 8, rank, nranks)
 slots = vpt.layout_slots(lay)

@@ -16,12 +16,12 @@ pytestmark = pytest.mark.gpu
 SCENE = os.path.join(GOLDEN, "scenes", "03_volume", "volume.json")
 
 
-def _run(tmp_path, tag, env, res, nranks, rank, spp, calls):
+def _run(tmp_path, tag, env, res, nranks, rank, spp, calls, scene=SCENE, shader="volpathtrace", bounces=64):
     out = str(tmp_path / f"{tag}.npz")
     e = dict(os.environ)
     e.update(env)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "render_rank_state.py"), SCENE, str(res), str(nranks), str(rank), str(spp), str(calls), out],
-                       env=e, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "render_rank_state.py"), scene, str(res), str(nranks), str(rank), str(spp), str(calls), out,
+                        shader, str(bounces)], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(out)
 
@@ -71,3 +71,17 @@ def test_a_small_frame_on_one_gpu_is_split_and_unchanged(tmp_path):
     assert _same_state(base, auto)
     print("720x300x32spp on one GPU: unsplit", base["ms"], "ms; split", auto["ms"], "ms")
     # (timing printed, not asserted; measured on MI355X at 256 spp: 212 -> 152 ms, profiles/r02_small_frames_tile_splitting.txt)
+
+
+@pytest.mark.parametrize("k", [1, 4])
+def test_split_tiles_of_the_implicit_kernel_give_the_same_state(tmp_path, k):
+    """K2 takes the same lane table (round 4): every tile of the voxel scene as 2^k partly filled waves - whose quorums scale with their pixels
+    and whose scene rounds run in the group form - ends in the unsplit state; and the default policy, which finds nothing to gain on a full
+    1280-wide frame (K2's partly filled waves are 0.82 / 0.67 / 0.63 as long as the full one: profiles/r04_k2_lane_histogram.txt), leaves it alone"""
+    sdf = os.path.join(GOLDEN, "scenes", "06_gridsdf_synth", "gridsdf_synth.json")
+    base = _run(tmp_path, "base", {"VPT_K2_SPLIT": "0"}, 320, 1, 0, 16, 3, scene=sdf, shader="implicit", bounces=4)
+    split = _run(tmp_path, f"k{k}", {"VPT_SPLIT_K": str(k)}, 320, 1, 0, 16, 3, scene=sdf, shader="implicit", bounces=4)
+    tiles = int(base["tiles"])
+    assert list(base["waves"]) == [tiles] * 3
+    assert list(split["waves"]) == [tiles, tiles << k, tiles << k]
+    assert _same_state(base, split)

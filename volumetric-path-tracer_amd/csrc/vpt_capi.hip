@@ -250,6 +250,7 @@ struct vpt_scene {
   std::vector<int> h_split_k;                   // per tile: it runs as 2^k waves
   bool      full_costs = false;                 // d_cost holds per-tile durations of an unsplit launch over >= 8 samples
   int       wave_slots_k1 = 3072;               // wave slots of the chip for K1 (CUs x 4 SIMDs x 3)
+  int       wave_slots_k2 = 5120;               // ... for K2 (x VPT_K2_WAVES)
   bool      split_decided = false;              // the decision for sched_key has been taken (costs of an unsplit launch were available)
   int       last_waves = 0;                     // grid of the last kernel launch (vpt_last_wave_costs)
   long long sched_waves = 0;       // waves the buffers are sized for
@@ -846,6 +847,7 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     s->wave_slots_k1 = prop.multiProcessorCount * 4 * VPT_WAVES_PER_SIMD;
+    s->wave_slots_k2 = prop.multiProcessorCount * 4 * VPT_K2_WAVES;
   }
   if (d.num_lights > 0) {   // element normals of the single-leaf mesh lights, by the device's own eval_element_normal
     hipLaunchKernelGGL(vpt_light_setup_kernel, dim3(d.num_lights), dim3(64), 0, 0, s->d, const_cast<float4*>(D.light_prims));
@@ -1032,6 +1034,7 @@ static void schedule_key(const launch_ctx& L, long long key[10]) {
 // not depend on it.
 static double split_gain[7] = {1.0, 0.75, 0.57, 0.44, 0.34, 0.27, 0.20};   // duration of a 64 >> k lane wave of a costly tile / its full wave (round 4's
                                                                            // kernel, whose partly filled waves use their empty lanes as helpers: 0.753 / 0.566 / 0.436 / 0.343 measured, was 0.81 / 0.62 / 0.45 / 0.35)
+static double split_gain_k2[7] = {1.0, 0.82, 0.67, 0.63, 0.60, 0.58, 0.56};   // the same for K2 (implicit shaders): 0.82 / 0.67 / 0.63 measured on 06_gridsdf_full (profiles/r04_k2_lane_histogram.txt), the rest extrapolated
 static double split_load0 = 0.46, split_margin = 0.98;   // load_factor's intercept; a split has to beat the unsplit launch by this factor
 static void split_tuning() {   // VPT_SPLIT_TUNE="g1,g2,g3,g4,g5,g6,load0,margin" (calibration runs only)
   static bool once = [] {
@@ -1104,7 +1107,7 @@ static double lpt_makespan(std::vector<double>& costs, int slots) {
 // A wave also runs faster when fewer waves share its SIMD: the costliest tile of 03_volume takes 273 ms with all 3 072
 // slots busy and 187 ms when 1 340 waves are resident: duration ~ (0.46 + 0.54 * occupancy) * duration at 1
 static double load_factor(double waves, int slots) { return split_load0 + (1 - split_load0) * std::min(1.0, waves / slots); }
-static int decide_split(vpt_scene* s, const DParams& pr, int ntiles, int slots, hipStream_t st) {
+static int decide_split(vpt_scene* s, const DParams& pr, int ntiles, int slots, hipStream_t st, const double* split_gain = ::split_gain) {
   s->split_decided = true, s->split_waves = 0, s->split_tiles = 0;
   split_tuning();
   HIP_TRY(hipStreamSynchronize(st));
@@ -1223,7 +1226,7 @@ static int launch_implicit(const launch_ctx& L) {
 #else
   long long key[10];
   schedule_key(L, key);
-  if (int rc = sched_prepare(s, L.grid.x, key, L.st)) return rc;
+  if (int rc = sched_prepare(s, std::max<long long>(L.grid.x, s->split_waves), key, L.st)) return rc;
   if (int rc = sched_wait(s, L.st)) return rc;
   size_t    lds = (size_t)s->stack_cap * VPT_BLOCK * sizeof(int) +                                      // refs-only stack
                (6 * (size_t)s->d.num_sdfs + 7 * (size_t)s->d.num_vol_instances) * sizeof(float4);       // the SDF records
@@ -1236,17 +1239,31 @@ static int launch_implicit(const launch_ctx& L) {
   int n = L.pr.nsamples, pilot = n / 64 < 1 ? 1 : n / 64 > 16 ? 16 : n / 64;
   int parts[2] = {(!s->order_valid && n >= 16 && !getenv("VPT_K2_NO_PILOT")) ? pilot : n, 0};
   parts[1] = n - parts[0];
+  // tile splitting as for K1 (above): K2's launches hold two waves per wave slot at 1280 x 533, so the longest-first schedule ends well
+  // above both of its bounds (226 ms against a longest wave of 192 and 191 of work per slot); the costliest tiles as partly filled waves -
+  // whose scene rounds run in the group form: four lanes per ray - pack better.  VPT_K2_SPLIT=0 switches it off.
+  static const bool k2_split = [] { const char* e = getenv("VPT_K2_SPLIT"); return !e || atoi(e) != 0; }();
+  const bool may_split = k2_split && split_mode() != 0;
   for (int part = 0; part < 2 && parts[part] > 0; part++) {
     DParams pr  = L.pr;
     pr.nsamples = parts[part];
     const bool is_pilot = parts[1] > 0 && part == 0;
-    sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, nullptr};
-    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, L.grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog, watchdog_ticks); };
+    if (may_split && !s->split_decided && s->order_valid && s->full_costs) {
+      HIP_TRY(hipEventRecord(s->ev_host0, L.st));
+      if (int rc = decide_split(s, pr, (int)L.grid.x, s->wave_slots_k2, L.st, split_gain_k2)) return rc;
+      HIP_TRY(hipEventRecord(s->ev_host1, L.st));
+      s->host_pause = true;
+    }
+    dim3 grid = s->split_waves > 0 ? dim3((unsigned)s->split_waves) : L.grid;
+    sched_cfg sch = {s->order_valid ? s->d_order : nullptr, s->d_cost, s->split_waves > 0 ? s->d_lane_slot : nullptr};
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, L.block, lds, L.st, s->d, pr, L.img, L.hit, L.rng, s->stack_cap, sch, s->d_watchdog, watchdog_ticks); };
     if (is_pilot && lean) launch(vpt_render_pilot_kernel<K, VPT_FEAT_SDF_LIGHTS>);
     else if (is_pilot) launch(vpt_render_pilot_kernel<K, VPT_FEAT_ALL>);
     else if (lean) launch(vpt_render_kernel<K, VPT_FEAT_SDF_LIGHTS>);
     else launch(vpt_render_kernel<K, VPT_FEAT_ALL>);
-    if (int rc = sched_update(s, L.grid.x, L.st)) return rc;
+    if (s->split_waves == 0) s->full_costs = pr.nsamples >= 8;
+    s->last_waves = (int)grid.x;
+    if (int rc = sched_update(s, grid.x, L.st)) return rc;
   }
   return VPT_OK;
 #endif

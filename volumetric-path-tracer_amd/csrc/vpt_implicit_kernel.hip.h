@@ -216,9 +216,13 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
   const int wave = sched.order ? sched.order[blockIdx.x] : (int)blockIdx.x;
 
   int slot = wave * VPT_BLOCK + threadIdx.x;
+  if (sched.lane_slot) slot = sched.lane_slot[slot];   // a split tile (vpt_capi.hip): this wave holds every 2^k-th pixel of it in its first lanes
   int px = 0, py = 0;
-  const bool owner = slot < pr.nslots && slot_to_pixel(pr, slot, px, py);   // padding lanes own no pixel: they stay M_DONE
+  const bool owner = slot >= 0 && slot < pr.nslots && slot_to_pixel(pr, slot, px, py);   // padding lanes own no pixel: they stay M_DONE
   if (__builtin_amdgcn_ballot_w64(owner) == 0) return;
+  // the quorums of the state machine are sized for 64 pixels: a partly filled wave scales them with its pixels
+  const int pixels = __popcll(__builtin_amdgcn_ballot_w64(owner));
+  const int shade_at = max(1, (VPT_K2_SHADE_AT * pixels + 63) >> 6), light_at = max(1, (VPT_K2_LIGHT_AT * pixels + 63) >> 6);
 
   // ---- pixel state: one coalesced read, kept in registers for the whole launch ----------------
   f4    acc = mk4(0, 0, 0, 0);
@@ -263,7 +267,7 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
     K2_STAT(KS_TRIPS, 1);
     K2_STAT(KS_DONE_LANES, 64 - __popcll(marching | waiting));
 
-    if (marching != 0 && __popcll(waiting) < VPT_K2_SHADE_AT) {
+    if (marching != 0 && __popcll(waiting) < shade_at) {
       // ---- march steps ------------------------------------------------------------------------------
       K2_STAT(KS_WAIT_LANES_AT_MARCH, __popcll(waiting));
       K2_CLOCK(c0);
@@ -310,7 +314,7 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
       // SDF-light marches: cheap steps (one analytic SDF), several per trip; lanes of one light at a time so that the
       // light's record is wave-uniform (scalar loads)
       unsigned long long lm = __builtin_amdgcn_ballot_w64(mode == M_LIGHT);
-      if (__popcll(lm) < VPT_K2_LIGHT_AT && __builtin_amdgcn_ballot_w64(mode == M_SCENE) != 0) lm = 0;   // too few: let them wait for company
+      if (__popcll(lm) < light_at && __builtin_amdgcn_ballot_w64(mode == M_SCENE) != 0) lm = 0;   // too few: let them wait for company
       if (lm != 0) {
         K2_STAT(KS_LIGHT_ROUNDS, 1);
         K2_STAT(KS_LIGHT_LANES, __popcll(lm));

@@ -462,3 +462,29 @@ def test_intersect_follows_the_reference_through_nan_hits(vpt, oracle, tmp_path)
             assert same.all(), (name, instance, np.nonzero(~same.all(axis=1))[0][:10])
             saw_nan += int(np.isnan(ruvt[:, 2]).sum())
     assert saw_nan > 100                                                           # the case this test is about did occur
+
+
+@pytest.mark.parametrize("scene_file,shader,res,bounces,spp", [
+    ("03_volume/volume.json", "volpathtrace", 1280, 64, 16),
+    ("05_head1ss_sub/head1ss_sub.json", "volpathtrace", 1280, 64, 4),
+    ("03_volume_lobes/volume_lobes.json", "volpathtrace", 640, 64, 8),
+    ("01_surface_min/surface_min.json", "pathtrace", 640, 4, 8),
+    ("06_gridsdf_full/gridsdf_full.json", "implicit", 1280, 4, 8),
+    ("07_sdfunction_synth/sdfunction_synth.json", "implicit", 640, 6, 8),
+])
+def test_group_forms_do_not_change_a_bit(vpt, monkeypatch, scene_file, shader, res, bounces, spp):
+    """Round 4's kernels run a phase that holds few rays on four lanes per ray (K1: node and leaf phases of traverse(); K2: the scene march).
+    VPT_NO_GROUP_FORMS=1 (read when a scene handle is created) keeps every ray in its own lane: the whole frame must come out bit for bit the
+    same - radiance sums, hit counts, RNG streams - at the BASELINE frame sizes, over batches, on every kind of scene."""
+    scene = vpt.HostScene(os.path.join(GOLDEN, "scenes", scene_file))
+    p = vpt.PathtraceParams(resolution=res, samples=1 << 20, shader=shader, bounces=bounces)
+    with_forms = vpt.DeviceScene(scene, 0)
+    monkeypatch.setenv("VPT_NO_GROUP_FORMS", "1")
+    without = vpt.DeviceScene(scene, 0)
+    monkeypatch.delenv("VPT_NO_GROUP_FORMS")
+    a, b = scene.make_state(p), scene.make_state(p)
+    with_forms.pathtrace_samples(a, p, spp)
+    without.pathtrace_samples(b, p, 1)
+    without.pathtrace_samples(b, p, spp - 1)
+    assert a.samples == b.samples == spp
+    assert np.array_equal(a.image.view(np.uint32), b.image.view(np.uint32)) and np.array_equal(a.rngs, b.rngs) and np.array_equal(a.hits, b.hits)

@@ -472,6 +472,7 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   D.num_materials = d.num_materials, D.num_textures = d.num_textures, D.num_environments = d.num_environments;
   D.num_volumes = d.num_volumes, D.num_vol_instances = d.num_vol_instances, D.num_sdfs = d.num_sdfs;
   D.num_lights = d.num_lights, D.num_scene_nodes = d.num_scene_bvh_nodes, D.num_scene_prims = d.num_scene_bvh_prims;
+  D.group_forms = getenv("VPT_NO_GROUP_FORMS") ? 0 : 1;   // A/B switch of the tests: the two forms of a phase must give the same bits
 
   // --- geometry pools in device layout ---------------------------------------------------------
   std::vector<float4> positions((size_t)d.num_positions), normals((size_t)d.num_normals), colors((size_t)d.num_colors);

@@ -88,7 +88,8 @@ struct DScene {
   //   root_ref, first quad node of the shape in scene_wnodes}, e5 = {leaf_offset, instance id, translation_only, num_nodes} (ints)
   const float4* scene_enter;      // 6 per scene-BVH primitive slot
   const int*    slot_of_instance; // instance id -> slot (single-instance queries)
-  int   scene_root_ref, pad1;
+  int   scene_root_ref;
+  int   group_forms;   // 1: phases with few rays run on four lanes per ray (traverse(), K2's scene march); 0 (VPT_NO_GROUP_FORMS=1): own forms only - same bits (tests)
   float scene_root_lo_x, scene_root_lo_y, scene_root_lo_z, scene_root_hi_x, scene_root_hi_y, scene_root_hi_z;
   // geometry
   const DInstance* instances;

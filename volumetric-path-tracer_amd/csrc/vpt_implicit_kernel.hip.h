@@ -272,7 +272,7 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
       K2_STAT(KS_WAIT_LANES_AT_MARCH, __popcll(waiting));
       K2_CLOCK(c0);
       const unsigned long long ms = __builtin_amdgcn_ballot_w64(mode == M_SCENE);
-      if (VPT_K2_GROUP_MAX > 0 && ms != 0 && __popcll(ms) <= VPT_K2_GROUP_MAX) {
+      if (VPT_K2_GROUP_MAX > 0 && sc.group_forms != 0 && ms != 0 && __popcll(ms) <= VPT_K2_GROUP_MAX) {
         // A small set of marching rays (a quarter of the scene rounds hold <= 16, a fifth <= 8: profiles/r04_k2_lane_histogram.txt): ray k of the
         // set on lanes 4k .. 4k+3 - whoever owns them: lanes whose pixel is finished, lanes that wait for the shading block - each lane
         // evaluating a quarter of the scene's SDFs per step (eval_sdf_scene_group); the ray's t sequence is the reference's, step for step

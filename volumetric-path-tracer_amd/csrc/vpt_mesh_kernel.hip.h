@@ -212,7 +212,7 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
   r.instance = -1, r.element = -1, r.uv = mk2(0, 0), r.distance = 0, r.hit = false, r.prim = 0;
   const float tmin = VPT_RAY_EPS;
   float tmax = VPT_FLT_MAX;
-  const bool whole_wave = __builtin_amdgcn_ballot_w64(true) == ~0ull;   // the group forms move data between lanes: all of them have to be here
+  const bool whole_wave = __builtin_amdgcn_ballot_w64(true) == ~0ull && sc.group_forms != 0;   // the group forms move data between lanes: all of them have to be here
   // (a lane without a ray holds whatever its last ray left in wo / wd: it must not steer the wave-wide choices of the reciprocal and slab forms)
   const f3   winv = rcp3_exact(active ? wd : mk3(1, 1, 1));
   const int  wsgn = sign_bits(winv);

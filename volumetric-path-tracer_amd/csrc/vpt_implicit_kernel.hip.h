@@ -239,8 +239,8 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
   // ---- path state --------------------------------------------------------------------------------
   int   mode = owner ? M_NEW : M_DONE;
   f3    ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);          // current ray (tmin = 1e-4, tmax = flt_max)
-  float t = VPT_RAY_EPS, lt = VPT_RAY_EPS;             // scene march / light march distance
-  int   it = 0, lit = 0, hit_instance = -1, hit_sdf = -1;
+  float t = VPT_RAY_EPS;                               // distance / step count of the march the lane is in: the scene march or - a lane never runs both at once:
+  int   it = 0, hit_instance = -1, hit_sdf = -1;       // the scene march's t is consumed when its hit is shaded, before the light walk starts - an SDF light's pdf march
   f3    radiance = mk3(0, 0, 0), weight = mk3(1, 1, 1);
   float alpha  = 0;
   int   bounce = 0, sample = 0;
@@ -326,7 +326,7 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
           const vpt_light& light = sc.lights[l];
           float area = sc.light_cdf[light.cdf_offset + light.cdf_len - 1];
           for (int k = 0; k < VPT_K2_LIGHT_STEPS; k++) {
-            if (mode == M_LIGHT && !light_march_step(recs, light.sdf, area, ro, rd, maxiter, lt, lit, lp_sum)) mode = M_LIGHTS, lp_light++;
+            if (mode == M_LIGHT && !light_march_step(recs, light.sdf, area, ro, rd, maxiter, t, it, lp_sum)) mode = M_LIGHTS, lp_light++;
             if (VPT_K2_LIGHT_EXIT && __builtin_amdgcn_ballot_w64(mode == M_LIGHT) == 0) break;   // every march of this light has ended
           }
         }
@@ -406,12 +406,12 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
           float4 r6 = sc.light_rec[8 * lp_light + 6], r7 = sc.light_rec[8 * lp_light + 7];
           int    kind = __float_as_int(r7.w) & 255;
           if (kind == VPT_LIGHT_SDF) {
-            lt = VPT_RAY_EPS, lit = 0;
+            t = VPT_RAY_EPS, it = 0;
             if (VPT_K2_LIGHT_INLINE != 0) {   // the march's first steps (all of them if < 0) here, in the shading block
               const vpt_light& light = sc.lights[lp_light];
               float area = sc.light_cdf[light.cdf_offset + light.cdf_len - 1];
               bool  alive = true;
-              for (int k = 0; alive && (VPT_K2_LIGHT_INLINE < 0 || k < VPT_K2_LIGHT_INLINE); k++) alive = light_march_step(recs, light.sdf, area, ro, rd, maxiter, lt, lit, lp_sum);
+              for (int k = 0; alive && (VPT_K2_LIGHT_INLINE < 0 || k < VPT_K2_LIGHT_INLINE); k++) alive = light_march_step(recs, light.sdf, area, ro, rd, maxiter, t, it, lp_sum);
               if (!alive) {
                 lp_light++;
                 continue;

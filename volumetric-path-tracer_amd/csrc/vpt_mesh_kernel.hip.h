@@ -209,16 +209,15 @@ __device__ unsigned g_vpt_guard_trips;   // diagnostic build: queries that were 
 template <class STK>
 VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_instance, const STK& stk) {
   hit_t r;
-  r.instance = -1, r.element = -1, r.uv = mk2(0, 0), r.distance = 0, r.hit = false, r.prim = 0;
+  r.instance = -1, r.element = -1, r.uv = mk2(0, 0), r.distance = 0, r.hit = false, r.prim = 0;   // (hit and distance are filled in at the end: instance >= 0, tmax)
   const float tmin = VPT_RAY_EPS;
   float tmax = VPT_FLT_MAX;
   const bool whole_wave = __builtin_amdgcn_ballot_w64(true) == ~0ull && sc.group_forms != 0;   // the group forms move data between lanes: all of them have to be here
   // (a lane without a ray holds whatever its last ray left in wo / wd: it must not steer the wave-wide choices of the reciprocal and slab forms)
   const f3   winv = rcp3_exact(active ? wd : mk3(1, 1, 1));
-  const int  wsgn = sign_bits(winv);
   bool       wslow = active && nan_prone(wd, winv);
   f3    co = wo, cd = wd, cinv = winv;
-  int   csgn = wsgn;
+  int   csgn = sign_bits(winv);
   bool  slow = wslow;
   int   sp = 0, shape_base = -1, pend = 0, cur_inst = -1, cur = VPT_NONE;
   int   wnb = 0, leafb = 0;   // the current level's quad nodes start at sc.scene_wnodes[8 * wnb], its leaf records at sc.leaf_prims[4 * leafb]
@@ -403,8 +402,8 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
       float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
       rec += 4;
       n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
-      if (intersect_quad(co, cd, tmin, tmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), r.uv, r.distance))
-        r.hit = true, r.element = __float_as_int(r0.w), r.instance = cur_inst, tmax = r.distance, r.prim = leafb + start + k;
+      if (intersect_quad(co, cd, tmin, tmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), r.uv, tmax))   // (an accepted hit's distance IS the new tmax)
+        r.instance = cur_inst, r.prim = leafb + start + k;
     }
     // A hit with a NaN distance (a triangle of denormal size met exactly at a corner: 0 * inf) leaves tmax = NaN, and the reference's
     // fmin(far, tmax) = (far < tmax) ? far : tmax then fails every later box test.  The hardware min / max of the fast box forms drop a
@@ -508,18 +507,16 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
     const int start = gcode >> 4, num = gact ? gcode & 15 : 0;
     bool  ghit = false, bad = gact && gtmax != gtmax;
     float gu = 0, gv = 0;
-    int   gelem = 0, gprim = 0;
+    int   gprim = 0;
     const int rounds = __builtin_amdgcn_ballot_w64(num > 4) != 0 ? 4 : 1;   // the reference's leaves hold <= 4 primitives; the format allows 15
     for (int b = 0; b < 4 * rounds; b += 4) {
       f2    uv = mk2(0, 0);
       float t = 0;
       bool  hit = false;
-      int   elem = 0;
       if (b + j < num && !bad) {
         const float4* rec = sc.leaf_prims + 4 * (long long)(gleafb + start + b + j);
         float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
         hit  = intersect_quad(gco, gcd, tmin, gtmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), uv, t);
-        elem = __float_as_int(r0.w);
       }
       bad = bad || quad_or(hit && t != t ? 1 : 0) != 0;
       // smallest t of the four, on a tie the later primitive (a hit's t is finite: t <= tmax <= flt_max)
@@ -533,15 +530,15 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
       take = ok < key || (ok == key && oi > idx);
       key = take ? ok : key, idx = take ? oi : idx;
       const bool win = j == idx && key < __builtin_inff();
-      const int  wu = quad_or(win ? __float_as_int(uv.x) : 0), wv = quad_or(win ? __float_as_int(uv.y) : 0), we = quad_or(win ? elem : 0);
-      if (key < __builtin_inff()) ghit = true, gtmax = key, gu = __int_as_float(wu), gv = __int_as_float(wv), gelem = we, gprim = gleafb + start + b + idx;
+      const int  wu = quad_or(win ? __float_as_int(uv.x) : 0), wv = quad_or(win ? __float_as_int(uv.y) : 0);
+      if (key < __builtin_inff()) ghit = true, gtmax = key, gu = __int_as_float(wu), gv = __int_as_float(wv), gprim = gleafb + start + b + idx;
     }
     // hand back: the owner of ray k reads lane 4k.  A group that met a NaN reports nothing: its owner walks the whole leaf itself
     const int src = mine ? rank << 2 : 0;
     const int nflag = pull(src, (ghit ? 1 : 0) | (bad ? 2 : 0));
     const float nt = pull(src, gtmax), nu = pull(src, gu), nv = pull(src, gv);
-    const int   ne = pull(src, gelem), np = pull(src, gprim);
-    if (mine && nflag == 1) r.hit = true, r.distance = nt, tmax = nt, r.uv = mk2(nu, nv), r.element = ne, r.prim = np, r.instance = cur_inst;
+    const int   np = pull(src, gprim);
+    if (mine && nflag == 1) tmax = nt, r.uv = mk2(nu, nv), r.prim = np, r.instance = cur_inst;
     return mine && (nflag & 2) != 0;
   };
 
@@ -584,7 +581,7 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
         if (shape_base < 0 || only_instance >= 0) done = true, go = false;   // nothing left: query finished
         else {   // leaving an instance: back to world space, then its leaf's next instance or the next scene entry
           shape_base = -1, wnb = 0;
-          cd = wd, cinv = winv, csgn = wsgn, slow = wslow;   // co: enter_pending
+          cd = wd, cinv = winv, csgn = sign_bits(winv), slow = wslow;   // co: enter_pending
         }
       } else pend = ~cur;   // a scene leaf: its instances are entered one after another, in order
       if (go) {
@@ -595,6 +592,9 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
     VPT_T1(TM_ENTER);
     if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
   }
+  r.hit = r.instance >= 0;
+  r.distance = r.hit ? tmax : 0;
+  if (r.hit) r.element = __float_as_int(sc.leaf_prims[4 * (long long)r.prim].w);   // the element id sits in the hit record: read once here rather than carried
   return r;
 }
 
@@ -746,17 +746,17 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
   float* const park = (float*)(lds_stack + stack.cap * 2 * VPT_BLOCK) + threadIdx.x;
   // Lanes that own no pixel (padding slots of a ragged frame, the empty lanes of a split tile) stay in the kernel: the whole wave
   // goes through every BVH query together, and a lane without a ray works on the others' rays there (traverse(): group forms)
-  bool owns;
+  // (no lane mask is kept for "owns a pixel" / "has samples left": both are read off slot, state and sample, which are there anyway -
+  // the kernel has no scalar register to spare)
   {
     int px0 = 0, py0 = 0;
-    owns = slot >= 0 && slot < pr.nslots && slot_to_pixel(pr, slot, px0, py0);
+    if (!(slot >= 0 && slot < pr.nslots && slot_to_pixel(pr, slot, px0, py0))) slot = -1;
     park[4 * VPT_BLOCK] = __int_as_float(px0 | (py0 << 16));
-    if (!owns) slot = 0;
   }
 
-  float4     acc_in = owns ? image[slot] : make_float4(0, 0, 0, 0);
+  float4     acc_in = slot >= 0 ? image[slot] : make_float4(0, 0, 0, 0);
   park[0] = acc_in.x, park[VPT_BLOCK] = acc_in.y, park[2 * VPT_BLOCK] = acc_in.z, park[3 * VPT_BLOCK] = acc_in.w;
-  ulonglong2 r_in   = owns ? rngs[slot] : make_ulonglong2(0, 1);
+  ulonglong2 r_in   = slot >= 0 ? rngs[slot] : make_ulonglong2(0, 1);
   rng_t      rng    = {r_in.x, r_in.y};
   const int  nb     = (SH == K_EYELIGHT) ? max(pr.bounces, 4) : pr.bounces;
   constexpr bool HAS_MIS = (SH == K_VOLPATH || SH == K_PATH);
@@ -776,10 +776,10 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
   int   lp_light = 0, lp_hop = 0;
   bool  mis_toggle = false;
 
-  bool alive = owns;   // this lane's pixel still has samples to render
+  if (slot < 0) sample = pr.nsamples;   // a lane without a pixel has nothing to render: it starts where the others end
   VPT_T0(TM_KERNEL);
   while (true) {
-    if (alive && state == ST_NEW && sample == pr.nsamples) alive = false;
+    const bool alive = !(state == ST_NEW && sample == pr.nsamples);   // this lane's pixel still has samples to render
     if (__builtin_amdgcn_ballot_w64(alive) == 0) break;   // wave-uniform: every lane stays until the tile is finished
     if (alive && state == ST_NEW) {
       VPT_CNT(CNT_GENERATE);
@@ -811,6 +811,11 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
     VPT_T0(TM_QUERY);
     hit_t h = traverse(sc, query, lpdf_query ? lp_pos : ray.o, ray.d, qinst, stk);
     VPT_T1(TM_QUERY);
+    if constexpr (!HAS_LARGE) {
+      // without light walks that span trips (ST_LPDF) a pending MIS evaluation never outlives its trip: say so, or its seven words
+      // stay allocated through every BVH query
+      mis_f = mk3(0, 0, 0), mis_pdf = 0, lp_sum = 0, lp_light = 0, mis_toggle = false;
+    }
     if (query) {
       VPT_CNT(CNT_TRIP);
 
@@ -1031,14 +1036,14 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
   if ((threadIdx.x & 63) == 0)   // lane 0 owns a pixel whenever the wave does (padding lanes sit at the end)
     for (int k = 0; k < 16; k++) atomicAdd(&g_vpt_cnt[32 + k], s_vpt_time[k]);
 #endif
-  if (owns) {
+  if (slot >= 0) {
     image[slot] = make_float4(park[0], park[VPT_BLOCK], park[2 * VPT_BLOCK], park[3 * VPT_BLOCK]);
     hits[slot] += pr.nsamples;
     ulonglong2 r_out;
     r_out.x = rng.state, r_out.y = rng.inc;
     rngs[slot] = r_out;
   }
-  if (sched.cost && threadIdx.x == 0 && owns) {   // lane 0 (the tile's corner pixel) exists whenever the wave owns a pixel
+  if (sched.cost && threadIdx.x == 0 && slot >= 0) {   // lane 0 (the tile's corner pixel) exists whenever the wave owns a pixel
     const unsigned long long wave_start = s_wave_start;
     unsigned long long dt = clock_ticks(slot) - wave_start;   // after the last sample was accumulated
     sched.cost[wave] = dt < 0xffffffffull ? (unsigned)dt : 0xffffffffu;

@@ -240,7 +240,7 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
   int   mode = owner ? M_NEW : M_DONE;
   f3    ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);          // current ray (tmin = 1e-4, tmax = flt_max)
   float t = VPT_RAY_EPS;                               // distance / step count of the march the lane is in: the scene march or - a lane never runs both at once:
-  int   it = 0, hit_instance = -1, hit_sdf = -1;       // the scene march's t is consumed when its hit is shaded, before the light walk starts - an SDF light's pdf march
+  int   it = 0, hit_id = -1;                            // what the scene march hit: a voxel-grid instance (>= 0) or an analytic SDF (~index)       // the scene march's t is consumed when its hit is shaded, before the light walk starts - an SDF light's pdf march
   f3    radiance = mk3(0, 0, 0), weight = mk3(1, 1, 1);
   float alpha  = 0;
   int   bounce = 0, sample = 0;
@@ -295,7 +295,7 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
         const float nt = pull(src, gt);
         if (mine) {
           mode = nmode, t = nt, it = nit;
-          if (nmode == M_HIT) hit_instance = nhi, hit_sdf = nhs;
+          if (nmode == M_HIT) hit_id = nhi >= 0 ? nhi : ~nhs;
         }
       } else if (ms != 0) {
         K2_STAT(KS_SCENE_ROUNDS, 1);
@@ -307,7 +307,11 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
         K2_STAT(KS_SCENE_LANES_LE32, __popcll(__builtin_amdgcn_ballot_w64(mode == M_SCENE)) <= 32 ? __popcll(__builtin_amdgcn_ballot_w64(mode == M_SCENE)) : 0);
         K2_STAT(KS_LIGHT_LANES_AT_SCENE, __popcll(__builtin_amdgcn_ballot_w64(mode == M_LIGHT)));
         for (int k = 0; k < VPT_K2_STEPS; k++)
-          if (mode == M_SCENE) mode = scene_march_step(sc, recs, ro, rd, maxiter, t, it, hit_instance, hit_sdf);
+          if (mode == M_SCENE) {
+            int hi = -1, hs = -1;
+            mode = scene_march_step(sc, recs, ro, rd, maxiter, t, it, hi, hs);
+            if (mode == M_HIT) hit_id = hi >= 0 ? hi : ~hs;
+          }
       }
       K2_CLOCK(c1);
       K2_LAP(KS_CLK_SCENE, c0, c1);
@@ -348,6 +352,7 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
       finish = true;
     } else if (mode == M_HIT) {
       f3 position = ro + rd * t;
+      const int hit_instance = hit_id >= 0 ? hit_id : VPT_INVALID, hit_sdf = hit_id >= 0 ? VPT_INVALID : ~hit_id;
       f3 normal   = hit_instance != VPT_INVALID ? eval_sdf_normal_grid(sc, recs, hit_instance, position, t)
                                                 : eval_sdf_normal_function(recs, hit_sdf, position, t);
       if constexpr (SH == K_IMPLICIT_NORMAL) {   // cpp:538-562
@@ -437,7 +442,7 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
       }
     }
     if (finish) {   // cpp:1087-1089
-      f4 rad = mk4(radiance.x, radiance.y, radiance.z, alpha);
+      f4 rad = mk4(radiance.x, radiance.y, radiance.z, SH == K_IMPLICIT ? 1.0f : alpha);   // (shade_implicit's alpha is always 1: no register for it)
       if (!(isfinite(rad.x) && isfinite(rad.y) && isfinite(rad.z) && isfinite(rad.w))) rad = mk4(0, 0, 0, 0);
       acc = acc + rad;
       sample++;

@@ -66,6 +66,18 @@ __global__ void vpt_light_cdf_selftest_kernel(DScene sc, int light_id, int n, un
   if (live && a != b) atomicAdd(&out[0], 1ull);
 }
 
+// Launch schedule: a wave's duration varies by +-17 % from one launch to the next on the same tile (it depends on which waves shared its SIMD:
+// profiles/r04_k2_lane_histogram.txt), and longest-first scheduling on such estimates ends well above its bound (K2: 225 ms against 203).  The order is
+// therefore taken from a running average of the duration PER SAMPLE (weight = samples seen, capped), whose bit pattern - positive floats - is the sort key.
+__global__ void vpt_cost_average_kernel(const unsigned* __restrict__ cost, float* __restrict__ avg, unsigned* __restrict__ key, int n, float nsamples, float weight) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float per_sample = (float)cost[i] / nsamples;
+  float a = weight > 0 ? (avg[i] * weight + per_sample * nsamples) / (weight + nsamples) : per_sample;
+  avg[i] = a;
+  key[i] = __float_as_uint(a);
+}
+
 // vpt_intersect: one lane per ray through the production traversal
 template <bool SPILL>
 __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_intersect_kernel(DScene sc, int n, const float* rays, int instance,
@@ -236,7 +248,9 @@ struct vpt_scene {
   void*              spill = nullptr;
   long long          spill_lanes = 0;
   // launch schedule of the mesh kernel (sched_cfg): per-wave cost of the last launch, waves by descending cost
-  unsigned *d_cost = nullptr, *d_cost_sorted = nullptr;
+  unsigned *d_cost = nullptr, *d_cost_sorted = nullptr, *d_cost_key = nullptr;
+  float*    d_cost_avg = nullptr;      // running average of a wave's duration per sample (vpt_cost_average_kernel)
+  float     cost_weight = 0;           // samples behind that average (0: none yet)
   int *     d_order = nullptr, *d_iota = nullptr;
   hipEvent_t  ev_order = nullptr;       // recorded after the sort that writes d_order
   hipStream_t order_stream = nullptr;   // the stream that sort ran on
@@ -445,7 +459,7 @@ void vpt_scene_destroy(vpt_scene* s) {
   for (void* p : {s->s_image, s->s_hits, s->s_rng, s->r_image, s->r_hits, s->r_rng})
     if (p) (void)hipFree(p);
   if (s->spill) (void)hipFree(s->spill);
-  for (void* p : {(void*)s->d_cost, (void*)s->d_cost_sorted, (void*)s->d_order, (void*)s->d_iota, s->sort_temp, (void*)s->d_lane_slot})
+  for (void* p : {(void*)s->d_cost, (void*)s->d_cost_sorted, (void*)s->d_cost_key, (void*)s->d_cost_avg, (void*)s->d_order, (void*)s->d_iota, s->sort_temp, (void*)s->d_lane_slot})
     if (p) (void)hipFree(p);
   if (s->ev_order) (void)hipEventDestroy(s->ev_order);
   if (s->d_watchdog) (void)hipFree(s->d_watchdog);
@@ -968,11 +982,13 @@ static int stack_config(vpt_scene* s, long long lanes, stack_cfg& cfg) {
 // Buffers of the launch schedule for `waves` waves; a change of layout / camera / shader forgets the measured costs.
 static int sched_prepare(vpt_scene* s, long long waves, const long long key[10], hipStream_t st) {
   if (waves > s->sched_waves) {
-    for (void** p : {(void**)&s->d_cost, (void**)&s->d_cost_sorted, (void**)&s->d_order, (void**)&s->d_iota, &s->sort_temp})
+    for (void** p : {(void**)&s->d_cost, (void**)&s->d_cost_sorted, (void**)&s->d_cost_key, (void**)&s->d_cost_avg, (void**)&s->d_order, (void**)&s->d_iota, &s->sort_temp})
       if (*p) (void)hipFree(*p), *p = nullptr;
-    s->sched_waves = 0, s->order_valid = false;
+    s->sched_waves = 0, s->order_valid = false, s->cost_weight = 0;
     HIP_TRY(hipMalloc((void**)&s->d_cost, waves * 4));
     HIP_TRY(hipMalloc((void**)&s->d_cost_sorted, waves * 4));
+    HIP_TRY(hipMalloc((void**)&s->d_cost_key, waves * 4));
+    HIP_TRY(hipMalloc((void**)&s->d_cost_avg, waves * 4));
     HIP_TRY(hipMalloc((void**)&s->d_order, waves * 4));
     HIP_TRY(hipMalloc((void**)&s->d_iota, waves * 4));
     HIP_TRY(hipMemset(s->d_cost, 0, waves * 4));   // waves that own no pixel never write theirs
@@ -985,14 +1001,26 @@ static int sched_prepare(vpt_scene* s, long long waves, const long long key[10],
     s->sort_temp_bytes = bytes, s->sched_waves = waves;
   }
   if (memcmp(key, s->sched_key, sizeof(s->sched_key)) != 0)
-    s->order_valid = false, s->split_decided = false, s->full_costs = false, s->split_waves = 0, s->split_tiles = 0, memcpy(s->sched_key, key, sizeof(s->sched_key));
+    s->order_valid = false, s->split_decided = false, s->full_costs = false, s->split_waves = 0, s->split_tiles = 0, s->cost_weight = 0, memcpy(s->sched_key, key, sizeof(s->sched_key));
   (void)st;
   return VPT_OK;
 }
 // order[] for the next launch from the costs the launch just enqueued on `st` will have written
-static int sched_update(vpt_scene* s, long long waves, hipStream_t st) {
+static float vpt_cost_horizon() {   // launches behind the running average (VPT_COST_HORIZON, calibration)
+  static const float h = [] { const char* e = getenv("VPT_COST_HORIZON"); return e ? (float)atof(e) : 6.0f; }();
+  return h < 1 ? 1 : h;
+}
+static int sched_update(vpt_scene* s, long long waves, hipStream_t st, int nsamples = 0) {
+  // nsamples > 0: d_cost holds the durations of a launch over that many samples: they enter the running average, whose order the next launch takes;
+  // nsamples == 0: d_cost holds predictions (a fresh split table): they start a new average
+  static const bool averaging = [] { const char* e = getenv("VPT_COST_AVERAGE"); return !e || atoi(e) != 0; }();
+  if (nsamples <= 0 || !averaging) s->cost_weight = 0;
+  const float n = nsamples > 0 ? (float)nsamples : 1.0f;
+  hipLaunchKernelGGL(vpt_cost_average_kernel, dim3((unsigned)((waves + 255) / 256)), dim3(256), 0, st, s->d_cost, s->d_cost_avg, s->d_cost_key, (int)waves, n, s->cost_weight);
+  HIP_TRY(hipGetLastError());
+  if (nsamples > 0 && averaging) s->cost_weight = std::min(s->cost_weight + n, vpt_cost_horizon() * n);   // the last few launches
   size_t bytes = s->sort_temp_bytes;
-  HIP_TRY(rocprim::radix_sort_pairs_desc(s->sort_temp, bytes, s->d_cost, s->d_cost_sorted, s->d_iota, s->d_order, (size_t)waves, 0, 32, st));
+  HIP_TRY(rocprim::radix_sort_pairs_desc(s->sort_temp, bytes, s->d_cost_key, s->d_cost_sorted, s->d_iota, s->d_order, (size_t)waves, 0, 32, st));
   HIP_TRY(hipEventRecord(s->ev_order, st));
   s->order_valid = true, s->order_stream = st;
   return VPT_OK;
@@ -1039,6 +1067,11 @@ static double split_gain_k2[7] = {1.0, 0.82, 0.67, 0.63, 0.60, 0.58, 0.56};   //
 static double split_load0 = 0.46, split_margin = 0.98;   // load_factor's intercept; a split has to beat the unsplit launch by this factor
 static void split_tuning() {   // VPT_SPLIT_TUNE="g1,g2,g3,g4,g5,g6,load0,margin" (calibration runs only)
   static bool once = [] {
+    if (const char* e = getenv("VPT_K2_SPLIT_TUNE")) {   // the same for the implicit kernels' table: "g1,g2,g3,g4,g5,g6"
+      double v[6];
+      if (sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", v, v + 1, v + 2, v + 3, v + 4, v + 5) == 6)
+        for (int i = 0; i < 6; i++) split_gain_k2[i + 1] = v[i];
+    }
     if (const char* e = getenv("VPT_SPLIT_TUNE")) {
       double v[8];
       if (sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7) == 8) {
@@ -1212,7 +1245,7 @@ static int launch_mesh(const launch_ctx& L) {
 #endif
     if (s->split_waves == 0) s->full_costs = pr.nsamples >= 8;   // d_cost now holds per-tile durations over enough samples (a pilot of a call with >= 512 samples counts)
     s->last_waves = (int)grid.x;
-    if (int rc = sched_update(s, grid.x, L.st)) return rc;
+    if (int rc = sched_update(s, grid.x, L.st, pr.nsamples)) return rc;
   }
   return VPT_OK;
 #endif
@@ -1264,7 +1297,7 @@ static int launch_implicit(const launch_ctx& L) {
     else launch(vpt_render_kernel<K, VPT_FEAT_ALL>);
     if (s->split_waves == 0) s->full_costs = pr.nsamples >= 8;
     s->last_waves = (int)grid.x;
-    if (int rc = sched_update(s, grid.x, L.st)) return rc;
+    if (int rc = sched_update(s, grid.x, L.st, pr.nsamples)) return rc;
   }
   return VPT_OK;
 #endif

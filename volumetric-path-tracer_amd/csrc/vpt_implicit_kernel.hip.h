@@ -490,6 +490,15 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
   if (sched.cost && threadIdx.x == 0) {
     unsigned long long dt = clock_ticks(__float_as_int(acc.x)) - wave_start;   // after the last sample was accumulated
     sched.cost[wave] = dt < 0xffffffffull ? (unsigned)dt : 0xffffffffu;
+#ifdef VPT_WAVE_TIMES
+    if (wave < 65536) {   // diagnostic build: the launch's occupancy timeline (profiles/tools/wave_slots.py), as K1 records it
+      g_vpt_wave_times[2 * wave] = wave_start, g_vpt_wave_times[2 * wave + 1] = wave_start + dt;
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_vpt_wave_hw[wave] = (xcc & 0xf) << 16 | (hw & 0xffff);
+    }
+#endif
   }
 }
 

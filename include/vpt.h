@@ -351,6 +351,13 @@ int vpt_check_watchdog(vpt_scene* scene);
  * their RNG streams).  VPT_SPLIT=0 disables it, VPT_SPLIT=1 considers it for every layout (it never pays on a full-size frame on one GPU). */
 int vpt_last_wave_costs(vpt_scene* scene, unsigned* ticks, int capacity, int* count);
 
+/* Bytes per primitive of the records the path tracers' BVH leaf tests / shading fetch on this scene: 64 / 96 in general (four corner
+ * positions; four normals + four texcoords), 48 / 64 when every shape of the scene holds triangles (three corners; three normals with the
+ * texcoords in their spare words).  Such a scene keeps both forms on the device: pathtrace and volpathtrace read the short ones on scenes
+ * without emissive meshes that need a BVH walk and without SDF lights, everything else reads the general ones.  Same results either way
+ * (VPT_NO_COMPACT_TRIANGLES=1 at scene creation keeps the general records only: the tests' A/B switch). */
+int vpt_scene_record_bytes(const vpt_scene* scene, int* leaf_bytes, int* attribute_bytes);
+
 /* intersect_bvh(bvh, scene, ray) (instance < 0) / intersect_bvh(bvh, scene, instance, ray) of yocto_bvh.h, for a
  * batch of `n` host rays {o.xyz, d.xyz} with the reference's default tmin = 1e-4, tmax = flt_max, through the
  * kernels' own traversal.  ids[2i..] = {instance, element} (-1, -1 on a miss), uvt[3i..] = {u, v, distance}.

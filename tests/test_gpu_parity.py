@@ -488,3 +488,57 @@ def test_group_forms_do_not_change_a_bit(vpt, monkeypatch, scene_file, shader, r
     without.pathtrace_samples(b, p, spp - 1)
     assert a.samples == b.samples == spp
     assert np.array_equal(a.image.view(np.uint32), b.image.view(np.uint32)) and np.array_equal(a.rngs, b.rngs) and np.array_equal(a.hits, b.hits)
+
+
+def _scene_of_triangles(tmp_path):
+    """08_subdiv_synth without its two quads (floor, area light): four tesselated shapes, with and without vertex normals / texcoords, textured
+    materials, lit by the environment - a scene whose shapes all hold triangles and whose BVHs fit the LDS stack."""
+    import json
+    src = os.path.join(GOLDEN, "scenes")
+    os.makedirs(tmp_path / "scene")
+    for name in ("03_volume", "shared_textures"):
+        os.symlink(os.path.join(src, name), tmp_path / name)
+    os.symlink(os.path.join(src, "08_subdiv_synth", "subdivs"), tmp_path / "scene" / "subdivs")
+    with open(os.path.join(src, "08_subdiv_synth", "subdiv_synth.json")) as f:
+        d = json.load(f)
+    keep = [1, 2, 3, 4]
+    d["shapes"] = [d["shapes"][i] for i in keep]
+    d["instances"] = [dict(inst, shape=keep.index(inst["shape"])) for inst in d["instances"] if inst["shape"] in keep]
+    d["subdivs"] = [dict(sd, shape=keep.index(sd["shape"])) for sd in d["subdivs"]]
+    path = tmp_path / "scene" / "triangles.json"
+    with open(path, "w") as f:
+        json.dump(d, f)
+    return str(path)
+
+
+@pytest.mark.parametrize("which,shader,res,bounces,spp", [
+    ("head", "volpathtrace", 640, 64, 4),      # 144 046 triangles, HBM-overflow stack instance
+    ("head", "pathtrace", 640, 8, 4),
+    ("subdiv", "pathtrace", 640, 8, 8),        # LDS-stack instance; shapes with and without normals / texcoords
+    ("subdiv", "volpathtrace", 640, 16, 8),
+    ("subdiv", "eyelight", 320, 4, 2),         # a shader without an instance for the short records: reads the general ones of the same scene
+])
+def test_compact_triangle_records_do_not_change_a_bit(vpt, monkeypatch, tmp_path, which, shader, res, bounces, spp):
+    """A scene whose shapes all hold triangles keeps 48-byte leaf records and 64-byte attribute records beside the general 64 / 96-byte ones, and
+    the path tracers' instances compiled for them read those (include/vpt.h: vpt_scene_record_bytes).  VPT_NO_COMPACT_TRIANGLES=1 (read when a
+    scene handle is created) keeps the general records only: the frame must come out bit for bit the same."""
+    scene_file = os.path.join(GOLDEN, "scenes", "05_head1ss_sub/head1ss_sub.json") if which == "head" else _scene_of_triangles(tmp_path)
+    scene = vpt.HostScene(scene_file)
+    p = vpt.PathtraceParams(resolution=res, samples=1 << 20, shader=shader, bounces=bounces)
+    compact = vpt.DeviceScene(scene, 0)
+    monkeypatch.setenv("VPT_NO_COMPACT_TRIANGLES", "1")
+    general = vpt.DeviceScene(scene, 0)
+    monkeypatch.delenv("VPT_NO_COMPACT_TRIANGLES")
+    assert compact.record_bytes() == (48, 64) and general.record_bytes() == (64, 96)
+    a, b = scene.make_state(p), scene.make_state(p)
+    compact.pathtrace_samples(a, p, spp)
+    general.pathtrace_samples(b, p, 1)
+    general.pathtrace_samples(b, p, spp - 1)
+    assert a.samples == b.samples == spp
+    assert np.array_equal(a.image.view(np.uint32), b.image.view(np.uint32)) and np.array_equal(a.rngs, b.rngs) and np.array_equal(a.hits, b.hits)
+    assert a.hits.sum() > 0
+
+
+def test_scenes_with_quads_keep_the_general_records(vpt):
+    dev = vpt.DeviceScene(vpt.HostScene(os.path.join(GOLDEN, "scenes", "03_volume/volume.json")), 0)
+    assert dev.record_bytes() == (64, 96)

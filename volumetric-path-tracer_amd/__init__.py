@@ -104,6 +104,7 @@ hip.vpt_last_kernel_ms.argtypes = [_p, C.POINTER(C.c_float)]
 hip.vpt_intersect.argtypes = [_p, C.c_int, _p, C.c_int, _p, _p]
 hip.vpt_build_bvh.argtypes = [C.c_int, _p, C.c_int, _p, C.c_int, C.POINTER(C.c_int), _p]
 hip.vpt_last_wave_costs.argtypes = [_p, _p, C.c_int, C.POINTER(C.c_int)]
+hip.vpt_scene_record_bytes.argtypes = [_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 hip.vpt_multi_create.argtypes = [_p, C.POINTER(C.c_int), C.c_int, C.POINTER(_p)]
 hip.vpt_multi_destroy.argtypes = [_p]
 hip.vpt_multi_destroy.restype = None
@@ -331,6 +332,12 @@ class DeviceScene:
         ms = C.c_float()
         _check(hip.vpt_last_kernel_ms(self.handle, C.byref(ms)), "vpt_last_kernel_ms")
         return ms.value
+
+    def record_bytes(self):
+        """(leaf record bytes, attribute record bytes) per primitive: (64, 96), or (48, 64) on a scene of triangles (include/vpt.h)"""
+        a, b = C.c_int(0), C.c_int(0)
+        _check(hip.vpt_scene_record_bytes(self.handle, C.byref(a), C.byref(b)), "vpt_scene_record_bytes")
+        return a.value, b.value
 
     def last_wave_costs(self) -> np.ndarray:
         """ticks (100 MHz) every wave of the last launch ran, indexed by wave (include/vpt.h)"""

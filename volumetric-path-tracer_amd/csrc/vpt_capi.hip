@@ -639,6 +639,23 @@ int vpt_scene_create(const vpt_scene_desc* desc, int device, vpt_scene** out) {
   leafs.resize(leafs.size() + 8, make_float4(0, 0, 0, 0));   // phase B fetches one record ahead of the one it tests
   UP(upload(s, leafs, &D.leaf_prims));
   UP(upload(s, leaf_attrs, &D.leaf_attrs));
+  {   // every shape holds triangles: the compact records beside the general ones (vpt_device.h: tri_prims / tri_attrs)
+    bool all_triangles = d.num_shapes > 0 && !getenv("VPT_NO_COMPACT_TRIANGLES");
+    for (int i = 0; i < d.num_shapes; i++) all_triangles = all_triangles && shapes[i].is_triangles && shapes[i].num_elems > 0;
+    D.tri_prims = D.tri_attrs = nullptr;
+    if (all_triangles) {
+      const size_t slots = leaf_attrs.size() / 6;
+      std::vector<float4> tp(3 * slots + 8, make_float4(0, 0, 0, 0)), ta(4 * slots);   // (+ 8: phase B fetches one record ahead, as above)
+      for (size_t k = 0; k < slots; k++) {
+        const float4 *p = &leafs[4 * k], *a = &leaf_attrs[6 * k];
+        for (int c = 0; c < 3; c++) tp[3 * k + c] = p[c], ta[4 * k + c] = a[c];
+        ta[4 * k + 0].w = a[4].x, ta[4 * k + 1].w = a[4].y, ta[4 * k + 2].w = a[4].z;
+        ta[4 * k + 3] = make_float4(a[4].w, a[5].x, a[5].y, 0);
+      }
+      UP(upload(s, tp, &D.tri_prims));
+      UP(upload(s, ta, &D.tri_attrs));
+    }
+  }
   {
     const size_t scene_count = scene_wnodes.size();
     if ((scene_count + shape_wnodes.size()) / 8 >= (1ull << 27)) return fail(VPT_ERR_UNSUPPORTED, "more than 2^27 quad nodes");
@@ -1237,9 +1254,18 @@ static int launch_mesh(const launch_ctx& L) {
     // three instances: single-leaf mesh lights only / + emissive meshes with a BVH / everything (SDF lights too)
 #if defined(VPT_EXPERIMENT_ONLY_VOLPATH)
     if (need != VPT_FEAT_SMALL_LIGHTS && (need & (VPT_FEAT_LARGE_LIGHTS | VPT_FEAT_SDF_LIGHTS)) != 0) return fail(VPT_ERR_UNSUPPORTED, "this experiment build holds the lean instance only");
-    launch_feat(std::integral_constant<int, VPT_FEAT_SMALL_LIGHTS>{});
+    if (s->d.tri_prims) {
+      if (L.stack.spill) launch(vpt_mesh_kernel<K, true, VPT_FEAT_SMALL_LIGHTS | VPT_FEAT_COMPACT_TRIS>);
+      else launch(vpt_mesh_kernel<K, false, VPT_FEAT_SMALL_LIGHTS | VPT_FEAT_COMPACT_TRIS>);
+    } else launch_feat(std::integral_constant<int, VPT_FEAT_SMALL_LIGHTS>{});
 #else
-    if ((need & (VPT_FEAT_LARGE_LIGHTS | VPT_FEAT_SDF_LIGHTS)) == 0) launch_feat(std::integral_constant<int, VPT_FEAT_SMALL_LIGHTS>{});
+    // (+ the compact-record form of the first for the two path tracers on scenes of triangles; the pilot runs on the general records)
+    if ((K == K_VOLPATH || K == K_PATH) && (need & (VPT_FEAT_LARGE_LIGHTS | VPT_FEAT_SDF_LIGHTS)) == 0 && s->d.tri_prims && !is_pilot) {
+      if constexpr (K == K_VOLPATH || K == K_PATH) {
+        if (L.stack.spill) launch(vpt_mesh_kernel<K, true, VPT_FEAT_SMALL_LIGHTS | VPT_FEAT_COMPACT_TRIS>);
+        else launch(vpt_mesh_kernel<K, false, VPT_FEAT_SMALL_LIGHTS | VPT_FEAT_COMPACT_TRIS>);
+      }
+    } else if ((need & (VPT_FEAT_LARGE_LIGHTS | VPT_FEAT_SDF_LIGHTS)) == 0) launch_feat(std::integral_constant<int, VPT_FEAT_SMALL_LIGHTS>{});
     else if ((need & VPT_FEAT_SDF_LIGHTS) == 0) launch_feat(std::integral_constant<int, VPT_FEAT_SMALL_LIGHTS | VPT_FEAT_LARGE_LIGHTS>{});
     else launch_feat(std::integral_constant<int, VPT_FEAT_ALL>{});
 #endif
@@ -1342,6 +1368,12 @@ int vpt_render_device(vpt_scene* s, const vpt_params* params, const vpt_layout* 
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev1, st));
   s->timed = true;
+  return VPT_OK;
+}
+
+int vpt_scene_record_bytes(const vpt_scene* s, int* leaf_bytes, int* attribute_bytes) {
+  if (!s || !leaf_bytes || !attribute_bytes) return fail(VPT_ERR_INVALID_ARG, "null argument");
+  *leaf_bytes = s->d.tri_prims ? 48 : 64, *attribute_bytes = s->d.tri_attrs ? 64 : 96;
   return VPT_OK;
 }
 

@@ -140,6 +140,13 @@ struct DScene {
   float sdf_bound_cx, sdf_bound_cy, sdf_bound_cz, sdf_bound_r;
   int   sdf_num_planes, pad3;
   const vpt_camera*          cameras;
+  // Compact records of a scene whose shapes all hold triangles (else null), beside the general ones above and in the same slot order:
+  // tri_prims: 3 float4 per slot = the three corners, element id in p0.w (48 bytes against 64);
+  // tri_attrs: 4 float4 per slot = {n0, t0.x} {n1, t0.y} {n2, t1.x} {t1.y, t2.x, t2.y, -} (64 bytes against 96).
+  // Read by the kernel instances compiled for them (VPT_FEAT_COMPACT_TRIS, vpt_scene.hip.h); a layout known at compile time costs the
+  // instances for quads nothing, the same choice taken at run time cost them 7 % (profiles/r04_record_layout.txt)
+  const float4* tri_prims;
+  const float4* tri_attrs;
 };
 
 struct DParams {

@@ -206,8 +206,9 @@ VPT_DEV bool slab_pass_signed(float nx, float ny, float nz, float fx, float fy, 
 #ifdef VPT_TRAVERSE_GUARD
 __device__ unsigned g_vpt_guard_trips;   // diagnostic build: queries that were cut short after VPT_TRAVERSE_GUARD loop rounds (must stay 0)
 #endif
-template <class STK>
+template <bool COMPACT = false, class STK>
 VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_instance, const STK& stk) {
+  constexpr int LS = COMPACT ? 3 : 4;   // float4 per leaf record
   hit_t r;
   r.instance = -1, r.element = -1, r.uv = mk2(0, 0), r.distance = 0, r.hit = false, r.prim = 0;   // (hit and distance are filled in at the end: instance >= 0, tmax)
   const float tmin = VPT_RAY_EPS;
@@ -395,13 +396,13 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
     VPT_CNT(CNT_LEAF);
     // software-pipelined: the next primitive's record is in flight while this one is tested (a leaf's
     // records are contiguous; one past the last primitive of the pool is still inside the padded array)
-    const float4* rec = sc.leaf_prims + 4 * (long long)(leafb + start);
-    float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+    const float4* rec = leaf_rec<COMPACT>(sc, leafb + start);
+    float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[LS - 1];   // (a compact record ends after its third corner: p3 = p2, the reference's triangle)
     for (int k = 0; k < num; k++) {
       VPT_CNT(CNT_PRIM);
       float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
-      rec += 4;
-      n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+      rec += LS;
+      n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[LS - 1];
       if (intersect_quad(co, cd, tmin, tmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), r.uv, tmax))   // (an accepted hit's distance IS the new tmax)
         r.instance = cur_inst, r.prim = leafb + start + k;
     }
@@ -514,8 +515,8 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
       float t = 0;
       bool  hit = false;
       if (b + j < num && !bad) {
-        const float4* rec = sc.leaf_prims + 4 * (long long)(gleafb + start + b + j);
-        float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        const float4* rec = leaf_rec<COMPACT>(sc, gleafb + start + b + j);
+        float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[LS - 1];
         hit  = intersect_quad(gco, gcd, tmin, gtmax, xyz(r0), xyz(r1), xyz(r2), xyz(r3), uv, t);
       }
       bad = bad || quad_or(hit && t != t ? 1 : 0) != 0;
@@ -594,7 +595,7 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
   }
   r.hit = r.instance >= 0;
   r.distance = r.hit ? tmax : 0;
-  if (r.hit) r.element = __float_as_int(sc.leaf_prims[4 * (long long)r.prim].w);   // the element id sits in the hit record: read once here rather than carried
+  if (r.hit) r.element = __float_as_int(leaf_rec<COMPACT>(sc, r.prim)[0].w);   // the element id sits in the hit record: read once here rather than carried
   return r;
 }
 
@@ -696,13 +697,14 @@ VPT_DEV float large_light_hop(const DScene& sc, int light_id, const hit_t& h, f3
 
 // The shading point of a surface hit: eval_shading_position, eval_shading_normal and eval_material
 // (yocto_scene.cpp:460-579) in one go.  `prim` is the hit's slot in leaf_prims / leaf_attrs.
+template <bool COMPACT = false>
 VPT_DEV void eval_surface_point(const DScene& sc, const DInstance& inst, const vpt_material& mat, int prim, int element, f2 uv,
     f3 outgoing, f3& position, f3& normal, mpoint& m) {
   f2 texcoord;
   f4 color_shp = mk4(1, 1, 1, 1);
   if ((inst.shape_flags & (VPT_SHP_NORMALS | VPT_SHP_COLORS)) == VPT_SHP_NORMALS) {
     // the common case: everything about the shading point sits behind the hit's primitive slot
-    eval_surface_slot(sc, inst, prim, uv, position, normal, texcoord);
+    eval_surface_slot<COMPACT>(sc, inst, prim, uv, position, normal, texcoord);
   } else {   // no vertex normals (element normal) or vertex colours: through the element's vertex indices
     position  = eval_position(sc, inst, element, uv);
     normal    = eval_normal(sc, inst, element, uv);
@@ -809,7 +811,7 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
     const bool lpdf_query = HAS_LARGE && query && state == ST_LPDF;
     const int  qinst      = lpdf_query ? sc.lights[lp_light].instance : -1;
     VPT_T0(TM_QUERY);
-    hit_t h = traverse(sc, query, lpdf_query ? lp_pos : ray.o, ray.d, qinst, stk);
+    hit_t h = traverse<(FEAT & VPT_FEAT_COMPACT_TRIS) != 0>(sc, query, lpdf_query ? lp_pos : ray.o, ray.d, qinst, stk);
     VPT_T1(TM_QUERY);
     if constexpr (!HAS_LARGE) {
       // without light walks that span trips (ST_LPDF) a pending MIS evaluation never outlives its trip: say so, or its seven words
@@ -867,7 +869,7 @@ VPT_DEV void mesh_kernel_body(const DScene& sc, const DParams& pr, float4* __res
         if (!in_volume) {
           const DInstance& inst = sc.instances[h.instance];
           VPT_T0(TM_SURF_GEOM);
-          eval_surface_point(sc, inst, sc.materials[inst.material], h.prim, h.element, h.uv, outgoing, position, normal, m);
+          eval_surface_point<(FEAT & VPT_FEAT_COMPACT_TRIS) != 0>(sc, inst, sc.materials[inst.material], h.prim, h.element, h.uv, outgoing, position, normal, m);
           VPT_T1(TM_SURF_GEOM);
           if (m.opacity < 1 && rand1f(rng) >= m.opacity) {
             ray = make_ray(position + ray.d * 1e-2f, ray.d);   // bounce -= 1; continue

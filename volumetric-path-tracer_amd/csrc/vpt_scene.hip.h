@@ -119,6 +119,13 @@ VPT_DEV bool intersect_bbox(f3 ro, f3 dinv, float tmin_, float tmax_, f3 bmin, f
   return t0 <= t1;
 }
 
+// a primitive slot's records (vpt_device.h: leaf_prims / leaf_attrs, or tri_prims / tri_attrs in the instances compiled for COMPACT)
+template <bool COMPACT>
+VPT_DEV const float4* leaf_rec(const DScene& sc, int slot) {
+  if constexpr (COMPACT) return sc.tri_prims + 3 * (long long)slot;
+  else return sc.leaf_prims + 4 * (long long)slot;
+}
+
 // shape-level traversal, yocto_bvh.cpp:699-797.  `sp0` is the stack level owned by the caller.
 VPT_DEV bool trace_shape(const DScene& sc, const DShape& sh, f3 ro, f3 rd, float tmin, float tmax,
     const lane_stack& stk, int sp0, int& element, f2& uv, float& distance) {
@@ -365,20 +372,26 @@ VPT_DEV mpoint eval_material(const DScene& sc, const DInstance& inst, int elemen
 // eval_position + eval_normal + eval_texcoord (yocto_scene.cpp:279-379) of a hit from its primitive slot: the same
 // corner choice (pick_corners), the same interpolation, the same values - fetched from leaf_prims / leaf_attrs.
 // Only for shapes with vertex normals and without vertex colours (the callers check shape_flags).
+template <bool COMPACT = false>
 VPT_DEV void eval_surface_slot(const DScene& sc, const DInstance& inst, int prim, f2 uv, f3& position, f3& normal, f2& texcoord) {
   int a, b, c;
   f2  w = uv;
   if (inst.shape_flags & VPT_SHP_TRIANGLES) a = 0, b = 1, c = 2;
   else if (uv.x + uv.y <= 1) a = 0, b = 1, c = 3;
   else a = 2, b = 3, c = 1, w = 1 - uv;
-  const float4* P = sc.leaf_prims + 4 * (long long)prim;
-  const float4* A = sc.leaf_attrs + 6 * (long long)prim;
+  const float4* P = leaf_rec<COMPACT>(sc, prim);
+  const float4* A = COMPACT ? sc.tri_attrs + 4 * (long long)prim : sc.leaf_attrs + 6 * (long long)prim;
   float4 pa = P[a], pb = P[b], pc = P[c], na = A[a], nb = A[b], nc = A[c];
   frame  f = unpack_frame(inst.fwd[0], inst.fwd[1], inst.fwd[2]);
   position = transform_point(f, tri_lerp(xyz(pa), xyz(pb), xyz(pc), w));
   normal   = transform_direction(f, normalize(tri_lerp(xyz(na), xyz(nb), xyz(nc), w)));
   texcoord = uv;
-  if (inst.shape_flags & VPT_SHP_TEXCOORDS) {
+  if constexpr (COMPACT) {
+    if (inst.shape_flags & VPT_SHP_TEXCOORDS) {   // a triangle's texcoords ride in the record's spare words
+      float4 t3 = A[3];
+      texcoord = tri_lerp(mk2(na.w, nb.w), mk2(nc.w, t3.x), mk2(t3.y, t3.z), w);
+    }
+  } else if (inst.shape_flags & VPT_SHP_TEXCOORDS) {
     const float2* T = (const float2*)(A + 4);
     float2 ta = T[a], tb = T[b], tc = T[c];
     texcoord = tri_lerp(mk2(ta.x, ta.y), mk2(tb.x, tb.y), mk2(tc.x, tc.y), w);
@@ -1074,7 +1087,8 @@ VPT_DEV st_hit spheretrace_one(const DScene& sc, f3 ro, f3 rd, int sdf_handle, i
 // Scene features a kernel instance is compiled for (template parameter FEAT of the mesh kernels): code for a feature the
 // scene does not have costs registers in every path (the allocator serves the worst one), so vpt_capi.hip launches the
 // instance without it - 03_volume, whose lights are quads and an environment: 622 -> 676 Msamples/s.
-enum { VPT_FEAT_LARGE_LIGHTS = 1,   // emissive meshes with a real BVH: sample_lights_pdf walks them with extra trips (ST_LPDF)
+enum { VPT_FEAT_COMPACT_TRIS = 8,   // not a light feature: the instance reads DScene::tri_prims / tri_attrs (scenes whose shapes all hold triangles)
+       VPT_FEAT_LARGE_LIGHTS = 1,   // emissive meshes with a real BVH: sample_lights_pdf walks them with extra trips (ST_LPDF)
        VPT_FEAT_SDF_LIGHTS   = 2,   // SDF lights: a sphere trace inside sample_lights_pdf
        VPT_FEAT_SMALL_LIGHTS = 4,   // emissive meshes of a single BVH leaf (area-light quads): walked inline from their light records
        VPT_FEAT_ALL          = 7 };

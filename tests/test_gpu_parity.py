@@ -542,3 +542,28 @@ def test_compact_triangle_records_do_not_change_a_bit(vpt, monkeypatch, tmp_path
 def test_scenes_with_quads_keep_the_general_records(vpt):
     dev = vpt.DeviceScene(vpt.HostScene(os.path.join(GOLDEN, "scenes", "03_volume/volume.json")), 0)
     assert dev.record_bytes() == (64, 96)
+
+
+def test_intersect_through_compact_records(vpt, oracle, monkeypatch, tmp_path):
+    """vpt_intersect takes the 48-byte leaf records on a scene of triangles (both stack variants of the traversal have an instance for them: the
+    head scene runs the HBM-overflow one in test_intersect_is_bit_identical_on_edge_case_rays, this scene the LDS one): same hits, bit for bit,
+    as through the general records and as the oracle's intersect_bvh - dense waves and waves with three rays (group forms of the leaf phase)."""
+    scene = vpt.HostScene(_scene_of_triangles(tmp_path))
+    compact = vpt.DeviceScene(scene, 0)
+    monkeypatch.setenv("VPT_NO_COMPACT_TRIANGLES", "1")
+    general = vpt.DeviceScene(scene, 0)
+    monkeypatch.delenv("VPT_NO_COMPACT_TRIANGLES")
+    assert compact.record_bytes()[0] == 48 and general.record_bytes()[0] == 64
+    rays = _edge_rays(np.random.default_rng(11), np.float32([-0.7, -0.05, -0.3]), np.float32([0.7, 0.35, 0.3]), 20000)
+    sparse = rays.copy()
+    sparse[(np.arange(len(rays)) * 7 + 3) % 64 >= 3] = np.float32([1e3, 1e3, 1e3, 0.57735027, 0.57735027, 0.57735027])
+    hits = 0
+    for batch in (rays, sparse):
+        for instance in (-1, 3):
+            ids, uvt = compact.intersect(batch, instance)
+            hits += int((ids[:, 0] >= 0).sum())
+            gids, guvt = general.intersect(batch, instance)
+            rids, ruvt = oracle.oracle_intersect(scene, batch, instance)
+            assert np.array_equal(ids, gids) and np.array_equal(uvt.view(np.uint32), guvt.view(np.uint32))
+            assert np.array_equal(ids, rids) and np.array_equal(uvt.view(np.uint32), ruvt.view(np.uint32))
+    assert hits > 300   # the batches do hit things

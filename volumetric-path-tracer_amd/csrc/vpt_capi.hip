@@ -17,6 +17,11 @@
 
 #include "vpt_implicit_kernel.hip.h"
 #include "vpt_kat_kernels.hip.h"
+#ifdef VPT_SPLIT_TUS   // the path tracers' instances of K1 are compiled in vpt_k1_volpath.hip / vpt_k1_path.hip
+#include "vpt_k1_instances.hip.h"
+VPT_K1_SPLIT_INSTANCES(VPT_K1_DECLARE, K_VOLPATH)
+VPT_K1_SPLIT_INSTANCES(VPT_K1_DECLARE, K_PATH)
+#endif
 #include <rocprim/rocprim.hpp>
 
 // light_prims of the single-leaf mesh lights (vpt_device.h): one thread per (light, primitive of the leaf)
@@ -78,8 +83,8 @@ __global__ void vpt_cost_average_kernel(const unsigned* __restrict__ cost, float
   key[i] = __float_as_uint(a);
 }
 
-// vpt_intersect: one lane per ray through the production traversal
-template <bool SPILL>
+// vpt_intersect: one lane per ray through the production traversal (COMPACT: the leaf records of a scene of triangles, as the path tracers read them)
+template <bool SPILL, bool COMPACT>
 __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_intersect_kernel(DScene sc, int n, const float* rays, int instance,
     int* ids, float* uvt, stack_cfg stack) {
   extern __shared__ int lds_stack[];
@@ -87,7 +92,7 @@ __global__ void __launch_bounds__(VPT_BLOCK, VPT_WAVES_PER_SIMD) vpt_intersect_k
   int i = blockIdx.x * VPT_BLOCK + threadIdx.x;
   const bool live = i < n;   // the whole wave goes through the query (traverse(): the group forms need every lane); surplus lanes carry no ray
   if (!live) i = 0;
-  hit_t h = traverse(sc, live, mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]), instance, stk);
+  hit_t h = traverse<COMPACT>(sc, live, mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]), instance, stk);
   if (!live) return;
   ids[2 * i] = h.hit ? h.instance : -1, ids[2 * i + 1] = h.hit ? h.element : -1;
   uvt[3 * i] = h.hit ? h.uv.x : 0, uvt[3 * i + 1] = h.hit ? h.uv.y : 0, uvt[3 * i + 2] = h.hit ? h.distance : 0;
@@ -1508,8 +1513,12 @@ int vpt_intersect(vpt_scene* s, int n, const float* rays, int instance, int32_t*
   stack_cfg stack;
   if (int rc = stack_config(s, (long long)blocks * VPT_BLOCK, stack)) { release(); return rc; }
   size_t lds = (size_t)s->stack_lds4 * 2 * VPT_BLOCK * sizeof(int);
-  if (stack.spill) hipLaunchKernelGGL(vpt_intersect_kernel<true>, dim3(blocks), dim3(VPT_BLOCK), lds, 0, s->d, n, d_rays, instance, d_ids, d_uvt, stack);
-  else hipLaunchKernelGGL(vpt_intersect_kernel<false>, dim3(blocks), dim3(VPT_BLOCK), lds, 0, s->d, n, d_rays, instance, d_ids, d_uvt, stack);
+  auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(blocks), dim3(VPT_BLOCK), lds, 0, s->d, n, d_rays, instance, d_ids, d_uvt, stack); };
+  if (s->d.tri_prims) {   // a scene of triangles: through the short leaf records, as its path tracers go
+    if (stack.spill) launch(vpt_intersect_kernel<true, true>);
+    else launch(vpt_intersect_kernel<false, true>);
+  } else if (stack.spill) launch(vpt_intersect_kernel<true, false>);
+  else launch(vpt_intersect_kernel<false, false>);
   bool ok = hipMemcpy(ids, d_ids, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(uvt, d_uvt, (size_t)n * 12, hipMemcpyDeviceToHost) == hipSuccess;
   release();
   return ok ? VPT_OK : fail(VPT_ERR_HIP, "vpt_intersect failed to run");

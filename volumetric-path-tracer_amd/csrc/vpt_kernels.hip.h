@@ -43,6 +43,7 @@ struct sched_cfg {
   const int* lane_slot;   // [wave][64] -> state slot of the lane (-1: none), or null: slot = wave * 64 + lane (one tile per wave).
                           // Set when costly tiles run as several partly filled waves (vpt_capi.hip: tile splitting)
 };
+#ifndef VPT_INSTANCES_TU   // (the translation units that only instantiate render kernels - vpt_k1_instances.hip.h - skip the plain kernels)
 // ---- state layout conversion and output resolve ---------------------------------------------
 // row-major host-order arrays <-> this rank's tile-major slots (vpt_state_upload / _download)
 __global__ void vpt_permute_kernel(DParams pr, int to_tiles, float4* tiles_image, int* tiles_hits, ulonglong2* tiles_rng,
@@ -87,3 +88,4 @@ __global__ void vpt_resolve_srgb8_kernel(DParams pr, const float4* tiles_all, fl
   rows_rgba8[(long long)py * pr.width + px] =
       make_uchar4(quant(curve(v.x * scale)), quant(curve(v.y * scale)), quant(curve(v.z * scale)), quant(v.w * scale));
 }
+#endif

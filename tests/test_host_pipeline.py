@@ -117,3 +117,34 @@ def test_jpeg_roundtrip_decodes(vpt):
     rgba = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)  # ragged size: edge replication
     img = np.asarray(Image.open(io.BytesIO(vpt.encode_jpeg_q75(rgba))).convert("RGB"))
     assert img.shape == (37, 53, 3)
+
+
+def test_byte_to_float_in_three_instructions_is_the_division():
+    """csrc/vpt_scene.hip.h: byte_to_float(b) = fma(fma(-255, q, b), r, q) with r = fl(1 / 255), q = fl(b * r) stands in for the reference's
+    b / 255.0f (yocto_color.h:212-214) in texture fetches.  Checked here in exact rational arithmetic with one correct rounding per operation
+    (what the device's v_mul_f32 / v_fma_f32 do): equal to the IEEE quotient for every byte."""
+    from fractions import Fraction
+    import math
+
+    def rnd(fr):   # round to nearest even float32, exactly
+        if fr == 0:
+            return np.float32(0)
+        a, e = abs(fr), math.floor(math.log2(abs(fr))) - 23
+        while a / Fraction(2) ** e >= 2 ** 24:
+            e += 1
+        while a / Fraction(2) ** e < 2 ** 23:
+            e -= 1
+        x = a / Fraction(2) ** e
+        m = x.numerator // x.denominator
+        rem = x - m
+        if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and (m & 1)):
+            m += 1
+        return np.float32(math.copysign(float(m) * 2.0 ** e, fr))
+
+    r = np.float32(1.0) / np.float32(255.0)
+    assert r.view(np.uint32) == 0x3B808081
+    for b in range(256):
+        q = rnd(Fraction(b) * Fraction(float(r)))
+        step = rnd(Fraction(b) - 255 * Fraction(float(q)))
+        got = rnd(Fraction(float(step)) * Fraction(float(r)) + Fraction(float(q)))
+        assert got.view(np.uint32) == (np.float32(b) / np.float32(255.0)).view(np.uint32), b

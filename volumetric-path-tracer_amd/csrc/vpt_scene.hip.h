@@ -179,6 +179,14 @@ VPT_DEV hit_t trace_instance(const DScene& sc, int instance, f3 o, f3 d, const l
 // ------------------------------------------------------------------------------------------------
 // textures, yocto_scene.cpp:112-169 ; sRGB decode through the host-built LUT (yocto_color.h:224-227)
 // ------------------------------------------------------------------------------------------------
+// byte_to_float, yocto_color.h:212-214: b / 255.0f.  The quotient of the IEEE division for every byte, in three instructions instead of
+// the eleven of a float32 division: one Newton step on b * fl(1 / 255) with fused multiply-adds (no overflow / underflow cases to guard for
+// operands 0 .. 255); equal to b / 255.0f for all 256 bytes (tests/test_host_pipeline.py checks the identity in exact arithmetic)
+VPT_DEV float byte_to_float(unsigned char b) {
+  const float rcp = __uint_as_float(0x3b808081u);   // fl(1 / 255)
+  const float x = (float)b, q = x * rcp;
+  return __builtin_fmaf(__builtin_fmaf(-255.0f, q, x), rcp, q);
+}
 VPT_DEV f4 lookup_texture(const DScene& sc, const vpt_texture& t, int i, int j, bool as_linear) {
   long long idx = t.offset + (long long)j * t.width + i;
   if (t.is_float) {
@@ -186,8 +194,8 @@ VPT_DEV f4 lookup_texture(const DScene& sc, const vpt_texture& t, int i, int j, 
     return mk4(v.x, v.y, v.z, v.w);   // linear textures are returned untouched
   }
   uchar4 b = sc.texels_b[idx];
-  if (as_linear && !t.linear) return mk4(sc.srgb_lut[b.x], sc.srgb_lut[b.y], sc.srgb_lut[b.z], b.w / 255.0f);
-  return mk4(b.x / 255.0f, b.y / 255.0f, b.z / 255.0f, b.w / 255.0f);
+  if (as_linear && !t.linear) return mk4(sc.srgb_lut[b.x], sc.srgb_lut[b.y], sc.srgb_lut[b.z], byte_to_float(b.w));
+  return mk4(byte_to_float(b.x), byte_to_float(b.y), byte_to_float(b.z), byte_to_float(b.w));
 }
 // fmod(x, 1.0f) (yocto_scene.cpp:141-144) without ocml's generic remainder loop: for finite x the
 // fractional part x - trunc(x) is exact in float32 and fmod's result carries the sign of x (also for a
@@ -203,7 +211,7 @@ VPT_DEV f4 eval_texture(const DScene& sc, int texture, f2 uv, bool as_linear) {
   float tt = fmod1(uv.y) * t.height;
   if (tt < 0) tt += t.height;
   int   i = clampi((int)s, 0, t.width - 1), j = clampi((int)tt, 0, t.height - 1);
-  int   ii = (i + 1) % t.width, jj = (j + 1) % t.height;
+  int   ii = i + 1 == t.width ? 0 : i + 1, jj = j + 1 == t.height ? 0 : j + 1;   // (i + 1) % width for 0 <= i < width, without the division
   float u = s - i, v = tt - j;
   return lookup_texture(sc, t, i, j, as_linear) * (1 - u) * (1 - v) + lookup_texture(sc, t, i, jj, as_linear) * (1 - u) * v +
          lookup_texture(sc, t, ii, j, as_linear) * u * (1 - v) + lookup_texture(sc, t, ii, jj, as_linear) * u * v;

@@ -25,8 +25,10 @@ all_gather_into_tensor, resolve of the gathered buffer) at world size 1, so that
 The JSON line carries, besides the driver's contract:
   roofline       algorithmic bytes per launch (SURVEY §8(d) formula, event counts measured by the CPU
                  oracle on a bounded sample of the same workload) / mean kernel time from HIP events
-                 on the launch stream, against the 8 TB/s HBM peak; `traffic` is the memory-side figure of the
-                 committed rocprofv3 PMC passes named by `traffic_source` (scaled to this launch), not a live counter.
+                 on the launch stream, against the 8 TB/s HBM peak; `traffic` is the memory-side figure of this launch: in the default
+                 run it is measured live - bench.py starts itself twice under rocprofv3 (--pmc FETCH_SIZE, then --pmc WRITE_SIZE, one
+                 launch each) after the timed region; otherwise (other workloads, no rocprofv3) the committed passes named by
+                 `traffic_source` are scaled to this launch.  `traffic_committed` keeps that replay beside the live figure.
   cpu_baseline   the reference's own renderer (oracle/_ref/ref_driver, "reference": all hardware threads as the
                  reference starts them, plus `single_thread`) and our CPU restatement at one thread per core (`port`),
                  timed on this host's cores on bounded samples of the same workload.  Rank 0, N=1 only.
@@ -284,6 +286,42 @@ class Bench:
                        "hbm": {"achieved": rec["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rec["frac"]}}
         return rec
 
+    def live_traffic(self, kernel="vpt_mesh_kernel", workload_args=()):
+        """Memory-side bytes of one launch of the default workload, measured NOW: two child runs of this script under
+        `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only: MI355X_MICROARCH.md, HBM section;
+        the program after `--` is python3 itself), the last dispatch of the kernel summed over its rows (XCDs).  Units are KB;
+        Infinity-Cache hits are included, so the figure is an upper bound on DRAM bytes.  Any failure returns {"error": ...} and the
+        line falls back to the committed passes of profiles/."""
+        import csv
+        import glob
+        import shutil
+        import subprocess
+        import tempfile
+        exe = shutil.which("rocprofv3")
+        if not exe:
+            return {"error": "rocprofv3 not found"}
+        out = {}
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="vpt_pmc_")
+            cmd = [exe, "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", d, "-o", "run", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--no-cold", "--no-others"] + list(workload_args)
+            try:
+                subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=env, cwd=ROOT)
+                rows = []
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    rows += [r for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
+                if not rows:
+                    return {"error": f"no {counter} rows for {kernel}"}
+                last = max(int(r["Dispatch_Id"]) for r in rows)
+                out[counter + "_KB"] = sum(float(r["Counter_Value"]) for r in rows if int(r["Dispatch_Id"]) == last)
+            except Exception as e:   # noqa: BLE001
+                return {"error": repr(e)[:300]}
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+        out["bytes_per_launch"] = (out["FETCH_SIZE_KB"] + out["WRITE_SIZE_KB"]) * 1024.0
+        return out
+
     def cpu_baseline(self, w):
         import oracle_lib
         vpt, args = self.vpt, self.args
@@ -386,6 +424,22 @@ def main():
 
     if rank == 0:
         roofline = B.roofline(w)
+        def with_live_traffic(rec, wl, kernel, workload_args):
+            # the counter passes of THIS run replace the replay from profiles/ (which stays as the fallback and as the per-round record)
+            live = B.live_traffic(kernel, workload_args)
+            if "bytes_per_launch" in live:
+                rec["traffic_committed"] = {"traffic": rec["traffic"], "source": rec["traffic_source"]}
+                rec["traffic"] = round(live["bytes_per_launch"])
+                rec["traffic_source"] = ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around child runs of this workload "
+                                         f"with --steps 1 --warmup 1, last dispatch of the kernel: FETCH_SIZE {live['FETCH_SIZE_KB']:.0f} KB + WRITE_SIZE {live['WRITE_SIZE_KB']:.0f} KB "
+                                         f"= {live['bytes_per_launch'] / wl.samples_per_step:.0f} B per sample (the write half is almost entirely register-spill scratch cycling "
+                                         "through L2, not data; Infinity-Cache hits count as traffic)")
+            else:
+                rec["traffic_live_error"] = live.get("error")
+            return rec
+        live_ok = world == 1 and default_workload and args.spp == 256 and not args.no_others and not args.dist
+        if live_ok:
+            with_live_traffic(roofline, w, "vpt_mesh_kernel", ())
         cpu_baseline = B.cpu_baseline(w) if (world == 1 and args.cpu_sample != "0") else None
         others = None
         if world == 1 and default_workload and not args.no_others:
@@ -401,6 +455,9 @@ def main():
                 others.append({"config": name, "workload": f"{wo.scene_name} {shader} bounces={bounces} {wo.width}x{wo.height}x{spp}spp per step",
                                "steps": 3, "warmup": 1, "ms_per_step": round(ms, 3), "value": round(wo.samples_per_step / ms * 1e-3, 3),
                                "unit": "Msamples/s", "cold": first, "roofline": B.roofline(wo)})
+                if live_ok:
+                    with_live_traffic(others[-1]["roofline"], wo, "vpt_render_kernel" if shader.startswith("implicit") else "vpt_mesh_kernel",
+                                      ["--scene", path, "--shader", shader, "--bounces", str(bounces), "--resolution", str(res), "--spp", str(spp)])
                 del wo
         rccl_path = None
         if world == 1 and default_workload and not args.no_others and not args.dist:

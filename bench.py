@@ -300,6 +300,8 @@ class Bench:
         exe = shutil.which("rocprofv3")
         if not exe:
             return {"error": "rocprofv3 not found"}
+        if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+            return {"error": "this run is itself under a profiler: no nested rocprofv3"}
         out = {}
         env = dict(os.environ, TMPDIR="/tmp")
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -286,7 +286,7 @@ class Bench:
                        "hbm": {"achieved": rec["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rec["frac"]}}
         return rec
 
-    def live_traffic(self, kernel="vpt_mesh_kernel", workload_args=()):
+    def live_traffic(self, kernel="vpt_mesh_kernel", workload_args=(), passes=(("FETCH_SIZE",), ("WRITE_SIZE",))):
         """Memory-side bytes of one launch of the default workload, measured NOW: two child runs of this script under
         `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only: MI355X_MICROARCH.md, HBM section;
         the program after `--` is python3 itself), the last dispatch of the kernel summed over its rows (XCDs).  Units are KB;
@@ -304,24 +304,27 @@ class Bench:
             return {"error": "this run is itself under a profiler: no nested rocprofv3"}
         out = {}
         env = dict(os.environ, TMPDIR="/tmp")
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counters in passes:
             d = tempfile.mkdtemp(prefix="vpt_pmc_")
-            cmd = [exe, "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", d, "-o", "run", "--",
+            cmd = [exe, "--kernel-trace", "--output-format", "csv", "--pmc", *counters, "-d", d, "-o", "run", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--no-cold", "--no-others"] + list(workload_args)
             try:
                 subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=env, cwd=ROOT)
                 rows = []
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                    rows += [r for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
+                    rows += [r for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"] and r["Counter_Name"] in counters]
                 if not rows:
-                    return {"error": f"no {counter} rows for {kernel}"}
+                    return {"error": f"no {counters} rows for {kernel}"}
                 last = max(int(r["Dispatch_Id"]) for r in rows)
-                out[counter + "_KB"] = sum(float(r["Counter_Value"]) for r in rows if int(r["Dispatch_Id"]) == last)
+                for counter in counters:
+                    out[counter + ("_KB" if counter.endswith("_SIZE") else "")] = sum(float(r["Counter_Value"]) for r in rows
+                                                                                      if int(r["Dispatch_Id"]) == last and r["Counter_Name"] == counter)
             except Exception as e:   # noqa: BLE001
                 return {"error": repr(e)[:300]}
             finally:
                 shutil.rmtree(d, ignore_errors=True)
-        out["bytes_per_launch"] = (out["FETCH_SIZE_KB"] + out["WRITE_SIZE_KB"]) * 1024.0
+        if "FETCH_SIZE_KB" in out and "WRITE_SIZE_KB" in out:
+            out["bytes_per_launch"] = (out["FETCH_SIZE_KB"] + out["WRITE_SIZE_KB"]) * 1024.0
         return out
 
     def cpu_baseline(self, w):
@@ -438,6 +441,18 @@ def main():
                                          "through L2, not data; Infinity-Cache hits count as traffic)")
             else:
                 rec["traffic_live_error"] = live.get("error")
+            if rec.get("bound") == "valu":   # K2: its VALU figures from a counter pass of this run as well
+                sq = B.live_traffic(kernel, workload_args, passes=(("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"),))
+                if sq.get("SQ_INSTS_VALU") and sq.get("SQ_ACTIVE_INST_VALU"):
+                    per_sample = sq["SQ_INSTS_VALU"] / wl.samples_per_step
+                    issued = per_sample * wl.samples_per_step / (rec["kernel_ms"] * 1e-3)
+                    rec["valu_committed"] = {"achieved": rec["achieved"], "frac": rec["frac"], "lane_utilisation": rec["lane_utilisation"], "source": rec["valu_source"]}
+                    rec["achieved"], rec["frac"] = round(issued * 1e-9, 2), round(issued / VALU_ISSUE_PEAK, 4)
+                    rec["lane_utilisation"] = round(sq["SQ_THREAD_CYCLES_VALU"] / (64.0 * sq["SQ_ACTIVE_INST_VALU"]), 4)
+                    rec["valu_source"] = (f"live: rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU around a child run of this workload ({per_sample:.0f} wave-level "
+                                          "VALU instructions per sample) x this run's samples/s / (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction)")
+                else:
+                    rec["valu_live_error"] = sq.get("error", "counters missing")
             return rec
         live_ok = world == 1 and default_workload and args.spp == 256 and not args.no_others and not args.dist
         if live_ok:

@@ -82,6 +82,10 @@ struct lane_stack2 {
       ref = e.x, t0 = __int_as_float(e.y);
     }
   }
+  // The HBM part is there for the worst case; a traversal rarely gets near it.  Wave-uniform shortcuts of the overflow variant: when no lane
+  // that is here can reach the HBM part with its next pushes (pops), the step runs the unchecked LDS code of the plain variant
+  VPT_DEV bool room_for(int sp, int entries) const { return !SPILL || __builtin_amdgcn_ballot_w64(sp + entries > cap) == 0; }
+  VPT_DEV void load_lds(int pos, int& ref, float& t0) const { ref = base[(2 * pos) * VPT_BLOCK], t0 = __int_as_float(base[(2 * pos + 1) * VPT_BLOCK]); }
   // the stack of another lane of this wave (the helper lanes of a group form work on their ray owner's column)
   VPT_DEV lane_stack2 of_lane(int lane) const {
     lane_stack2 s = *this;
@@ -227,11 +231,14 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
   // pop entries of the current level until one passes the reference's pop-time box test
   auto pop_valid = [&]() {
     int base = shape_base >= 0 ? shape_base : 0;
+    const bool lds_only = stk.room_for(sp, 0);   // sp only falls from here on
     while (sp > base) {
       int   ref;
       float t0;
       VPT_CNT(CNT_POP);
-      stk.pop(sp, ref, t0);
+      sp--;
+      if (lds_only) stk.load_lds(sp, ref, t0);
+      else stk.load(sp, ref, t0);
       if (t0 <= tmax * VPT_BOX_K) return ref;
     }
     return VPT_NONE;
@@ -360,9 +367,9 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
     // push the later-visited ones (last first); the first-visited one is taken directly: it would be
     // popped next with the same tmax, so its pop test is a tautology
     int next;
-    if constexpr (!STK::spills) {
+    if (stk.room_for(sp, 4)) {
       // branch-free: every candidate is stored; one that is not pushed lands on the free entry above the new
-      // top (the host sizes the LDS part one entry larger than the worst case)
+      // top (the host sizes the LDS part one entry larger than the worst case; the overflow variant takes this path while all lanes have room)
       bool f0 = v0 != VPT_NONE, f1 = v1 != VPT_NONE, f2 = v2 != VPT_NONE, f3 = v3 != VPT_NONE;
       bool q3 = f3 && (f2 || f1 || f0), q2 = f2 && (f1 || f0), q1 = f1 && f0;
       int  top = sp + (int)q3 + (int)q2 + (int)q1;
@@ -467,17 +474,22 @@ VPT_DEV hit_t traverse(const DScene& sc, bool active, f3 wo, f3 wd, int only_ins
         const int kfirst = pv ? __builtin_ctz(pv) : 4;
         // the first-visited one is the next node (popped next with the same tmax: its pop test is a tautology); the others are
         // pushed last-visited first: rank k lands above the passing ranks greater than k
-        if (present && k > kfirst) gstk.store(gsp + __builtin_popcount(pv >> (k + 1)), rj, t0);
+        if (present && k > kfirst) {
+          if (gstk.room_for(gsp, 4)) gstk.put(gsp + __builtin_popcount(pv >> (k + 1)), rj, t0);
+          else gstk.store(gsp + __builtin_popcount(pv >> (k + 1)), rj, t0);
+        }
         const int next = quad_or(present && k == kfirst ? rj : 0);
         gsp += pv ? __builtin_popcount(pv) - 1 : 0;
         gcur = next;
         if (!pv) {   // pop_valid on the owner's column; the four lanes of a group read the same entries
           gcur = VPT_NONE;
+          const bool lds_only = gstk.room_for(gsp, 0);
           while (gsp > gfloor) {
             int   pref;
             float pt0;
             gsp--;
-            gstk.load(gsp, pref, pt0);
+            if (lds_only) gstk.load_lds(gsp, pref, pt0);
+            else gstk.load(gsp, pref, pt0);
             if (pt0 <= gtmax * VPT_BOX_K) {
               gcur = pref;
               break;

@@ -461,10 +461,13 @@ def main():
         others = None
         if world == 1 and default_workload and not args.no_others:
             others = []
+            # Each at its BASELINE sample count per step (config 5's frame: 256 of its 4096): a lane runs its pixel's samples one after the other and a wave
+            # ends with its slowest lane, so the share of a wave's time spent waiting for that lane falls with the length of the chain (config 3: 790 /
+            # 842 / 870 Msamples/s at 64 / 256 / 1024 samples per launch, profiles/r04_full_spp_configs.txt) - rounds 1-4 quoted these records at 64 / 128 / 64
             for name, path, shader, bounces, res, spp in (
-                    ("config3 (tests/05_head1ss: assets missing, substitute scene)", os.path.join(SCENES, "05_head1ss_sub", "head1ss_sub.json"), "volpathtrace", 64, 1280, 64),
-                    ("config4 (tests/06_gridsdf: assets missing, substitute scene with 96^3 + 64^3 grids)", os.path.join(SCENES, "06_gridsdf_full", "gridsdf_full.json"), "implicit", 4, 1280, 128),
-                    ("config5's frame on one GPU", SCENE, "volpathtrace", 64, 3840, 64)):
+                    ("config3 (tests/05_head1ss: assets missing, substitute scene)", os.path.join(SCENES, "05_head1ss_sub", "head1ss_sub.json"), "volpathtrace", 64, 1280, 1024),
+                    ("config4 (tests/06_gridsdf: assets missing, substitute scene with 96^3 + 64^3 grids)", os.path.join(SCENES, "06_gridsdf_full", "gridsdf_full.json"), "implicit", 4, 1280, 512),
+                    ("config5's frame on one GPU", SCENE, "volpathtrace", 64, 3840, 256)):
                 wo = B.workload(path, shader, bounces, res, spp)
                 first = B.cold_call(wo)
                 eo = B.timed(wo, 3, 1)

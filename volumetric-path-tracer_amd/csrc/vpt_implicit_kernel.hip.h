@@ -75,7 +75,7 @@
 #define VPT_K2_GROUP_MAX 16  // scene-march rounds with at most this many marching rays run four lanes per ray (0: never)
 #endif
 #ifndef VPT_K2_STEPS
-#define VPT_K2_STEPS 8       // march steps between two looks at the wave's state (2: -5 %, 4: -1.5 %, 8: best)
+#define VPT_K2_STEPS 12      // march steps between two looks at the wave's state (round 2: 2: -5 %, 4: -1.5 %, 8: best; end of round 4, 512 samples per launch: 8: 408 / 175.7, 12: 416.5 / 177.2, 16: 416.5 / 177.0, 24: 415.3 / 173.1 Msamples/s on 06_gridsdf_full / 07_sdfunction_synth)
 #endif
 
 // Diagnostic build (-DVPT_K2_STATS): where the lanes of a wave are, trip by trip (profiles/tools/k2_stats.py).  Never in the product build.
@@ -257,7 +257,7 @@ __device__ __forceinline__ void implicit_kernel_body(const DScene& sc, const DPa
   while (true) {
     // every wave reaches an exit: the state machine ends when all lanes are M_DONE; should a defect ever keep it from
     // getting there, the wave gives up after watchdog_ticks (VPT_K2_WATCHDOG_TICKS) of the 100 MHz clock and the launch reports it
-    if (((++trips) & 255) == 0 && clock_ticks(trips) - wave_start > watchdog_ticks) {
+    if (((trips++) & 255) == 0 && clock_ticks(trips) - wave_start > watchdog_ticks) {   // looked at on the first trip and on every 256th
       gave_up = true;
       break;
     }
